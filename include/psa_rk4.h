@@ -1,0 +1,157 @@
+/*
+ * psa_rk4.h -- C-ABI of libpsa_hip.so: the MI355X (gfx950) drop-in for the
+ * reference's RK4 / Agrawal-Yaman hot path.
+ *
+ * The reference (Alxkov/PSA-simulation-ODE-RK-MVP-Dispersion) is pure Python and
+ * has no FFI; its de-facto operator API is three nested call surfaces
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it
+ * replaces (file:line into the upstream tree).  The binding a maintainer adds on
+ * the reference side is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer;
+ *   - return value: 0 ok, < 0 argument error (PSA_E_*), > 0 a hipError_t;
+ *     psa_last_error() gives the message for the calling thread;
+ *   - a per-point NUMERICAL failure (NaN/Inf) is never a return code: it is
+ *     reported in first_bad_step[N] (the reference raises FloatingPointError
+ *     per run, integrators.py:132-135, and its sweep drivers turn that into a
+ *     NaN gain, scan_mismtach.py:391-392);
+ *   - "host" functions are blocking and take host pointers in NumPy layout
+ *     (complex128 = interleaved re,im); "_dev" functions take device (HBM)
+ *     pointers in SoA layout and are asynchronous on the given hipStream_t;
+ *   - thread-safe for distinct devices/streams; no global mutable state except
+ *     the per-thread error string.
+ *
+ * Wave order everywhere: [pump1, pump2, signal, idler] (n_waves = 4) or
+ * [pump1, pump2, signal1, idler1, signal2, idler2] (n_waves = 6, build-defined
+ * extension; the reference has no 6-wave model).  The gain summary is taken on
+ * wave index 2 (the signal), as scan_mismtach.py:376 does.
+ */
+#ifndef PSA_RK4_H
+#define PSA_RK4_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- argument-error codes (negative) ------------------------------------- */
+#define PSA_OK            0
+#define PSA_E_NWAVES     -1   /* n_waves not 4 or 6                                  */
+#define PSA_E_NPOINTS    -2   /* n_points < 0                                        */
+#define PSA_E_NSTEPS     -3   /* n_steps <= 0                                        */
+#define PSA_E_ZMAX       -4   /* z_max <= 0 or not finite  (integrators.py:188-189)  */
+#define PSA_E_SAVE_EVERY -5   /* save_every <= 0           (integrators.py:108-109)  */
+#define PSA_E_NULLPTR    -6   /* a required pointer is NULL                          */
+#define PSA_E_DEVICE     -7   /* device index out of range / no gfx950 device        */
+#define PSA_E_DBETA2     -8   /* n_waves == 6 needs dbeta2; n_waves == 4 forbids it  */
+#define PSA_E_TOO_LARGE  -9   /* trajectory buffer size overflows int64              */
+
+/* ---- flags ----------------------------------------------------------------- */
+/* broadcast: the array has ONE entry used for every sweep point */
+#define PSA_BCAST_GAMMA      (1u << 0)
+#define PSA_BCAST_ALPHA      (1u << 1)
+#define PSA_BCAST_A0         (1u << 2)
+/* options */
+#define PSA_OPT_CHECK_NAN    (1u << 8)   /* SimulationConfig.check_nan (config.py:29): track first_bad_step over ALL
+                                            n_steps (also the tail after the last saved row).  Without it
+                                            first_bad_step is -1 everywhere and NaNs propagate silently.         */
+#define PSA_OPT_EXACT_STEP   (1u << 9)   /* with CHECK_NAN: test finiteness after EVERY step (exact index, as
+                                            integrators.py:132).  Without it the test runs once per save block and
+                                            first_bad_step is the LAST step of the first non-finite block (the
+                                            sweep drivers only need "did it fail").                              */
+#define PSA_OPT_LDS_STAGING  (1u << 10)  /* keep y / y_stage / k-accumulator in LDS instead of VGPRs (the layout
+                                            the north-star sketches; slower -- kept for the A/B in DESIGN.md)    */
+#define PSA_OPT_BLOCK64      (1u << 11)  /* 64-thread workgroups (one wave) instead of 256                       */
+
+/* ---- environment ----------------------------------------------------------- */
+int         psa_device_count(void);          /* number of visible HIP devices (0 if none / no driver) */
+const char *psa_last_error(void);            /* message of the last failure on this thread            */
+const char *psa_version(void);               /* "psa-hip <semver> gfx950"                              */
+int64_t     psa_n_saved(int64_t n_steps, int32_t save_every);   /* n_steps / save_every + 1, integrators.py:115 */
+
+/* ---- B3/B2: the sweep (host buffers, blocking) ----------------------------------
+ * Replaces the body of the per-point loops scan_mismtach.py:357-392 and :694-738, i.e.
+ * N x { simulation.run_single_simulation (simulation.py:349-357) -> integrators.integrate_interval
+ * (integrators.py:150-204) -> integrate_fixed_step (:68-142) -> rk4_step (:25-61) ->
+ * yaman_model.rhs_yaman_simplified (yaman_model.py:10-52) } plus the reduction
+ * P3 = |A[:,2]|^2, max / last over saved rows (scan_mismtach.py:376-381, :27-40).
+ *
+ *   n_steps    = int(round(z_max/dz)) computed by the caller (integrators.py:194);
+ *                the kernel steps on z_i = i * (z_max / n_steps)  (np.linspace, :195)
+ *   dbeta      [N]   phase mismatch per point, 1/length          (parameters.py:236 CacheParams.delta_beta_1_m)
+ *   dbeta2     [N]   second pair's mismatch (n_waves == 6) or NULL
+ *   gamma      [N] | [1]    fiber.gamma_W_m   (parameters.py:166)
+ *   alpha      [N] | [1]    fiber.alpha_1_m
+ *   a0_re_im   [N][n_waves][2] | [1][n_waves][2]   initial amplitudes (simulation.py:103-123)
+ *   a_end_re_im[N][n_waves][2]   state at the LAST SAVED row = step (n_steps/save_every)*save_every
+ *   p_sig_end  [N]   |A_sig|^2 at that row            (gain_mode "end", scan_mismtach.py:36-37)
+ *   p_sig_max  [N]   max over saved rows incl. z = 0  (gain_mode "max", :38-39; NaN-propagating like np.max)
+ *   first_bad_step [N]  -1, or the 0-based step index after which the state was non-finite
+ *   traj_or_null   [N][n_saved][n_waves][2]  every saved row (integrators.py:137-140), or NULL
+ *   elapsed_ms_or_null  kernel time from hipEvents on the launch stream, or NULL
+ */
+int psa_rk4_sweep_f64(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max,
+                      int32_t save_every, const double *dbeta, const double *dbeta2, const double *gamma,
+                      const double *alpha, const double *a0_re_im, uint32_t flags, double *a_end_re_im,
+                      double *p_sig_end, double *p_sig_max, int64_t *first_bad_step, double *traj_or_null,
+                      double *elapsed_ms_or_null);
+
+/* float32 state/arithmetic variant (BASELINE config 4; build-defined, the reference forces complex128,
+ * yaman_model.py:41-44).  The phase dbeta*z is still formed in float64.  z_max stays double. */
+int psa_rk4_sweep_f32(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max,
+                      int32_t save_every, const float *dbeta, const float *dbeta2, const float *gamma,
+                      const float *alpha, const float *a0_re_im, uint32_t flags, float *a_end_re_im,
+                      float *p_sig_end, float *p_sig_max, int64_t *first_bad_step, float *traj_or_null,
+                      double *elapsed_ms_or_null);
+
+/* ---- the same sweep on buffers already resident in HBM (async on `stream`) -------
+ * Device layout is SoA so that every wave instruction is a contiguous 512-B (f64) access:
+ *   d_a0_soa    [2*n_waves][N] (or [2*n_waves][1] with PSA_BCAST_A0): row 2j = Re A_j, 2j+1 = Im A_j
+ *   d_a_end_soa [2*n_waves][N]
+ *   d_traj_soa  [n_saved][2*n_waves][N] or NULL
+ * `stream` is a hipStream_t (NULL = default stream).  No allocation, no synchronisation: safe to capture
+ * into a hipGraph.  This is what bench.py times and what the multi-GPU path calls per rank.
+ */
+int psa_rk4_sweep_f64_dev(void *stream, int n_waves, int64_t n_points, int64_t n_steps, double z_max,
+                          int32_t save_every, const double *d_dbeta, const double *d_dbeta2,
+                          const double *d_gamma, const double *d_alpha, const double *d_a0_soa, uint32_t flags,
+                          double *d_a_end_soa, double *d_p_sig_end, double *d_p_sig_max,
+                          int64_t *d_first_bad_step, double *d_traj_soa);
+
+int psa_rk4_sweep_f32_dev(void *stream, int n_waves, int64_t n_points, int64_t n_steps, double z_max,
+                          int32_t save_every, const float *d_dbeta, const float *d_dbeta2, const float *d_gamma,
+                          const float *d_alpha, const float *d_a0_soa, uint32_t flags, float *d_a_end_soa,
+                          float *d_p_sig_end, float *d_p_sig_max, int64_t *d_first_bad_step, float *d_traj_soa);
+
+/* ---- B1': one RHS evaluation per point (host buffers, blocking) --------------------
+ * Replaces yaman_model.rhs_yaman_simplified (yaman_model.py:10-52) for a batch:
+ *   z [N], a_re_im [N][4][2], gamma/alpha/dbeta [N]  ->  out_re_im [N][4][2]
+ * and, when non-NULL, the three terms of yaman_model.py:123-132 / :135-156 / :159-186.
+ */
+int psa_yaman_rhs_f64(int device, int64_t n_points, const double *z, const double *a_re_im,
+                      const double *gamma, const double *alpha, const double *dbeta, double *out_re_im,
+                      double *out_linear, double *out_kerr, double *out_fwm);
+
+/* ---- gain summary over a finished sweep (host buffers, blocking) -------------------
+ * Per-point reduction of scan_mismtach.py:376-389 / :723-734 and the argmax-over-sweep summary of the
+ * (dead) scan_mismatch_seeded_signal (scan_mismtach.py:183-186), as one wavefront/block reduction:
+ *   gain[i] = p_metric[i] / p0_sig  (linear) or 10*log10 of it (gain_db != 0);
+ *             NaN if p_metric is not finite, gain <= 0, or first_bad_step[i] >= 0
+ *   *best_index = argmax over finite gains (-1 if none), *best_gain its value, *n_finite their count.
+ */
+int psa_gain_summary_f64(int device, int64_t n_points, const double *p_metric, const int64_t *first_bad_step,
+                         double p0_sig, int gain_db, double *gain_out, int64_t *best_index, double *best_gain,
+                         int64_t *n_finite);
+
+int psa_gain_summary_f64_dev(void *stream, int64_t n_points, const double *d_p_metric,
+                             const int64_t *d_first_bad_step, double p0_sig, int gain_db, double *d_gain_out,
+                             int64_t *d_best_index, double *d_best_gain, int64_t *d_n_finite,
+                             void *d_workspace /* >= psa_gain_summary_workspace_bytes(n_points) */);
+int64_t psa_gain_summary_workspace_bytes(int64_t n_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSA_RK4_H */

@@ -1,0 +1,223 @@
+"""ctypes binding of ``libpsa_hip.so`` (the C-ABI declared in ``include/psa_rk4.h``).
+
+This is the ONLY compute path of the package: there is no CPU fallback.  If the
+shared library is missing, or no gfx950 device is visible when a compute entry
+point is called, a ``NativeUnavailableError`` / ``PsaNativeError`` is raised.
+
+Two faces:
+
+* ``sweep_host`` / ``yaman_rhs_host`` / ``gain_summary_host`` take NumPy arrays
+  (host buffers, blocking) -- what the reference-shaped Python API uses;
+* ``sweep_device`` takes raw device pointers + a hipStream_t handle (e.g. from
+  torch tensors) -- what ``bench.py`` and the multi-GPU driver use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libpsa_hip.so")
+
+# flags (mirror include/psa_rk4.h)
+BCAST_GAMMA = 1 << 0
+BCAST_ALPHA = 1 << 1
+BCAST_A0 = 1 << 2
+OPT_CHECK_NAN = 1 << 8
+OPT_EXACT_STEP = 1 << 9
+OPT_LDS_STAGING = 1 << 10
+OPT_BLOCK64 = 1 << 11
+
+# every symbol the header declares, with (restype, argtypes)
+_P = C.c_void_p
+_SIGS = {
+    "psa_device_count": (C.c_int, []),
+    "psa_last_error": (C.c_char_p, []),
+    "psa_version": (C.c_char_p, []),
+    "psa_n_saved": (C.c_int64, [C.c_int64, C.c_int32]),
+    "psa_rk4_sweep_f64": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
+                                    _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "psa_rk4_sweep_f32": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
+                                    _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "psa_rk4_sweep_f64_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
+                                        _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P]),
+    "psa_rk4_sweep_f32_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
+                                        _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P]),
+    "psa_yaman_rhs_f64": (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "psa_gain_summary_f64": (C.c_int, [C.c_int, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P]),
+    "psa_gain_summary_f64_dev": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
+    "psa_gain_summary_workspace_bytes": (C.c_int64, [C.c_int64]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class NativeUnavailableError(RuntimeError):
+    """libpsa_hip.so cannot be loaded (not built, or the HIP runtime is missing)."""
+
+
+class PsaNativeError(RuntimeError):
+    """A C-ABI call returned non-zero (argument error < 0, hipError_t > 0)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libpsa_hip rc={code}: {message}")
+        self.code = code
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once; raise loudly if it is not there."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeUnavailableError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                "(or `make -C psa-simulation-ode-rk-mvp-dispersion_amd/csrc`). There is no CPU fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise NativeUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the build is stale
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def device_count() -> int:
+    return int(lib().psa_device_count())
+
+
+def version() -> str:
+    return lib().psa_version().decode()
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise PsaNativeError(rc, lib().psa_last_error().decode(errors="replace"))
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _prep(x, dtype, n_points: int, name: str):
+    """-> (contiguous 1-D array, is_broadcast)."""
+    arr = np.ascontiguousarray(np.atleast_1d(np.asarray(x)), dtype=dtype)
+    if arr.ndim != 1:
+        raise ValueError(f"{name} must be a scalar or 1-D array")
+    if arr.shape[0] == n_points and n_points != 1:
+        return arr, False
+    if arr.shape[0] == 1:
+        return arr, True
+    raise ValueError(f"{name} must have 1 or {n_points} entries, got {arr.shape[0]}")
+
+
+def sweep_host(dbeta, *, n_steps: int, z_max: float, save_every: int, gamma, alpha, a0, dbeta2=None,
+               check_nan: bool = True, exact_step: bool = False, want_traj: bool = False, dtype=np.float64,
+               device: int = 0, extra_flags: int = 0) -> dict:
+    """Run N independent RK4 propagations on the GPU (host buffers in, host buffers out).
+
+    dbeta (N,); gamma/alpha scalar or (N,); a0 (n_waves,) or (N, n_waves) complex.
+    Returns a_end (N, n_waves) complex, p_end, p_max (N,), first_bad_step (N,) int64,
+    traj (N, n_saved, n_waves) complex or None, elapsed_ms (kernel only).
+    """
+    dtype = np.dtype(dtype)
+    if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError("dtype must be float64 or float32")
+    cdt = np.complex128 if dtype == np.float64 else np.complex64
+    dbeta = np.ascontiguousarray(np.atleast_1d(np.asarray(dbeta)), dtype=dtype)
+    if dbeta.ndim != 1:
+        raise ValueError("dbeta must be 1-D")
+    N = int(dbeta.shape[0])
+    a0 = np.ascontiguousarray(np.asarray(a0), dtype=cdt)
+    if a0.ndim == 1:
+        a0 = a0[None, :]
+    if a0.ndim != 2 or a0.shape[1] not in (4, 6):
+        raise ValueError("a0 must have shape (n_waves,) or (N, n_waves) with n_waves in (4, 6)")
+    nw = int(a0.shape[1])
+    flags = int(extra_flags)
+    if a0.shape[0] == 1:
+        flags |= BCAST_A0
+    elif a0.shape[0] != N:
+        raise ValueError(f"a0 must have 1 or {N} rows, got {a0.shape[0]}")
+    gamma, gb = _prep(gamma, dtype, N, "gamma")
+    alpha, ab = _prep(alpha, dtype, N, "alpha")
+    if gb:
+        flags |= BCAST_GAMMA
+    if ab:
+        flags |= BCAST_ALPHA
+    if check_nan:
+        flags |= OPT_CHECK_NAN
+        if exact_step:
+            flags |= OPT_EXACT_STEP
+    d2 = None
+    if nw == 6:
+        if dbeta2 is None:
+            raise ValueError("n_waves == 6 needs dbeta2")
+        d2 = np.ascontiguousarray(np.atleast_1d(np.asarray(dbeta2)), dtype=dtype)
+        if d2.shape != dbeta.shape:
+            raise ValueError("dbeta2 must match dbeta")
+    elif dbeta2 is not None:
+        raise ValueError("dbeta2 is only meaningful for 6 waves")
+
+    n_saved = int(n_steps) // int(save_every) + 1 if save_every > 0 else 0
+    a_end = np.empty((N, nw), dtype=cdt)
+    p_end = np.empty(N, dtype=dtype)
+    p_max = np.empty(N, dtype=dtype)
+    bad = np.empty(N, dtype=np.int64)
+    traj = np.empty((N, n_saved, nw), dtype=cdt) if want_traj else None
+    ms = C.c_double(0.0)
+    fn = lib().psa_rk4_sweep_f64 if dtype == np.float64 else lib().psa_rk4_sweep_f32
+    _check(fn(int(device), nw, N, int(n_steps), float(z_max), int(save_every), _ptr(dbeta), _ptr(d2), _ptr(gamma),
+              _ptr(alpha), _ptr(a0), flags, _ptr(a_end), _ptr(p_end), _ptr(p_max), _ptr(bad), _ptr(traj),
+              C.cast(C.byref(ms), C.c_void_p)))
+    return dict(a_end=a_end, p_end=p_end, p_max=p_max, first_bad_step=bad, traj=traj, elapsed_ms=ms.value)
+
+
+def sweep_device(*, stream: int, n_waves: int, n_points: int, n_steps: int, z_max: float, save_every: int,
+                 d_dbeta: int, d_dbeta2: int, d_gamma: int, d_alpha: int, d_a0_soa: int, flags: int,
+                 d_a_end_soa: int, d_p_end: int, d_p_max: int, d_first_bad: int, d_traj_soa: int = 0,
+                 dtype=np.float64) -> None:
+    """Asynchronous launch on device pointers (ints), SoA layout -- see psa_rk4_sweep_f64_dev."""
+    fn = lib().psa_rk4_sweep_f64_dev if np.dtype(dtype) == np.float64 else lib().psa_rk4_sweep_f32_dev
+    _check(fn(stream or None, int(n_waves), int(n_points), int(n_steps), float(z_max), int(save_every),
+              d_dbeta or None, d_dbeta2 or None, d_gamma or None, d_alpha or None, d_a0_soa or None, int(flags),
+              d_a_end_soa or None, d_p_end or None, d_p_max or None, d_first_bad or None, d_traj_soa or None))
+
+
+def yaman_rhs_host(z, a, gamma, alpha, dbeta, *, terms: bool = False, device: int = 0):
+    """Batched yaman_model.rhs_yaman_simplified on the GPU: a (N,4) complex -> (N,4) complex."""
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.complex128)
+    if a.ndim == 1:
+        a = a[None, :]
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("a_arr must have shape (4,)")
+    N = a.shape[0]
+    bc = lambda x: np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (N,)))  # noqa: E731
+    z, gamma, alpha, dbeta = bc(z), bc(gamma), bc(alpha), bc(dbeta)
+    out = np.empty((N, 4), dtype=np.complex128)
+    parts = [np.empty((N, 4), dtype=np.complex128) for _ in range(3)] if terms else [None, None, None]
+    _check(lib().psa_yaman_rhs_f64(int(device), N, _ptr(z), _ptr(a), _ptr(gamma), _ptr(alpha), _ptr(dbeta),
+                                   _ptr(out), _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2])))
+    return (out, *parts) if terms else out
+
+
+def gain_summary_host(p_metric, first_bad_step, p0_sig: float, *, gain_db: bool = True, device: int = 0):
+    """Per-point gain (NaN on failure) + (argmax, max, #finite) over the sweep, reduced on the GPU."""
+    p = np.ascontiguousarray(np.asarray(p_metric), dtype=np.float64)
+    bad = None if first_bad_step is None else np.ascontiguousarray(np.asarray(first_bad_step), dtype=np.int64)
+    N = p.shape[0]
+    gain = np.empty(N, dtype=np.float64)
+    bi = C.c_int64(-1)
+    bg = C.c_double(float("nan"))
+    nf = C.c_int64(0)
+    _check(lib().psa_gain_summary_f64(int(device), N, _ptr(p), _ptr(bad), float(p0_sig), int(bool(gain_db)),
+                                      _ptr(gain), C.cast(C.byref(bi), _P), C.cast(C.byref(bg), _P),
+                                      C.cast(C.byref(nf), _P)))
+    return gain, int(bi.value), float(bg.value), int(nf.value)

@@ -1,0 +1,52 @@
+// psa_internal.h -- shared between the kernel TUs and the C-ABI TU (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psa {
+
+// Everything one sweep launch needs; passed by value as the kernel argument.
+// All pointers are device pointers.  Strides are in elements: 1 = per point, 0 = broadcast.
+template <typename T>
+struct SweepArgs {
+    const T *dbeta;      // [N]
+    const T *dbeta2;     // [N] (6-wave) or nullptr
+    const T *gamma;      // [N] | [1]
+    const T *alpha;      // [N] | [1]
+    const T *a0;         // SoA [2*NW][a0_ld]; a0_ld = N (per point) or 1 (broadcast, stride 0)
+    T *a_end;            // SoA [2*NW][N]
+    T *p_end;            // [N]
+    T *p_max;            // [N]
+    long long *first_bad;  // [N]
+    T *traj;             // SoA [n_saved][2*NW][N] or nullptr
+    long long n_points;
+    double z_max;
+    int n_steps;
+    int save_every;
+    int gamma_stride, alpha_stride, a0_stride;  // 0 | 1
+    long long a0_ld;
+};
+
+enum CheckMode : int { CHECK_NONE = 0, CHECK_BLOCK = 1, CHECK_EXACT = 2 };
+
+// launchers (defined in psa_rk4_f64.hip / psa_rk4_f32.hip)
+hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<double> &a);
+hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<float> &a);
+
+// aux kernels (psa_aux.hip)
+hipError_t launch_aos_to_soa_f64(hipStream_t s, const double *aos, double *soa, long long n, int nc);
+hipError_t launch_soa_to_aos_f64(hipStream_t s, const double *soa, double *aos, long long n, int nc);
+hipError_t launch_aos_to_soa_f32(hipStream_t s, const float *aos, float *soa, long long n, int nc);
+hipError_t launch_soa_to_aos_f32(hipStream_t s, const float *soa, float *aos, long long n, int nc);
+// traj: soa [rows][nc][n] -> aos [n][rows][nc]
+hipError_t launch_traj_to_aos_f64(hipStream_t s, const double *soa, double *aos, long long n, long long rows, int nc);
+hipError_t launch_traj_to_aos_f32(hipStream_t s, const float *soa, float *aos, long long n, long long rows, int nc);
+hipError_t launch_yaman_rhs_f64(hipStream_t s, long long n, const double *z, const double *a, const double *gamma,
+                                const double *alpha, const double *dbeta, double *out, double *lin, double *kerr,
+                                double *fwm);
+hipError_t launch_gain_summary_f64(hipStream_t s, long long n, const double *p_metric, const long long *first_bad,
+                                   double p0_sig, int gain_db, double *gain_out, long long *best_index,
+                                   double *best_gain, long long *n_finite, void *workspace);
+long long gain_summary_workspace_bytes(long long n);
+
+}  // namespace psa

@@ -1,0 +1,275 @@
+// psa_rk4_kernel.inc.h -- the RK4 sweep kernel for gfx950 (included by psa_rk4_f64.hip / psa_rk4_f32.hip).
+//
+// One sweep point per lane, the whole z-loop inside the kernel, state in VGPRs.
+// Replaces, per point:  integrators.integrate_fixed_step (integrators.py:68-142) driving
+// integrators.rk4_step (:25-61) on yaman_model.rhs_yaman_simplified (yaman_model.py:10-52),
+// plus the saved-row reduction of the sweep drivers (scan_mismtach.py:376-381).
+//
+// What bounds it: FP64 vector FMA issue (16 lanes/clk/SIMD on CDNA4), NOT HBM and not MFMA:
+// a point reads 8..88 B and writes 88 B for its entire z-loop, and the RHS is an elementwise
+// complex polynomial (no contraction to tile).  So the design rules here are
+//   * minimum DP instructions per step (320 for 4 waves; see the count in DESIGN.md),
+//   * no transcendental in the steady-state loop: E(z) = 2*gamma*exp(i*dbeta*z) is carried by a
+//     complex rotation per half step and re-seeded from an exact sincos every RESYNC steps
+//     (bounds the recurrence drift at ~1e-14, far inside the 1e-9 parity budget),
+//   * <= 128 VGPRs so 4 waves/SIMD stay resident, all per-lane arrays statically indexed,
+//   * wave-uniform control flow only (save stride, resync and NaN tracking never diverge),
+//   * SoA global layout: every load/store instruction of a wave is one contiguous 512-B run.
+//
+// The independent variable follows the reference grid: z_i = i * (z_max / n_steps)
+// (np.linspace, integrators.py:195) formed from the INTEGER step index, never accumulated.
+#pragma once
+#include "psa_internal.h"
+
+namespace psa {
+
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// cos/sin of a float64 phase, delivered in the working precision.
+template <typename T> struct Phase;
+template <> struct Phase<double> {
+    static constexpr int RESYNC = 64;  // steps between exact re-seeds of the rotation recurrence
+    static __device__ __forceinline__ void eval(double ph, double &c, double &s) { sincos(ph, &s, &c); }
+};
+template <> struct Phase<float> {
+    static constexpr int RESYNC = 16;
+    // dbeta*z reaches 1e4..1e5 rad at 1e6 steps: reduce in f64, then an f32 sincos on [-pi, pi].
+    static __device__ __forceinline__ void eval(double ph, float &c, float &s) {
+        const double r = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
+        sincosf((float)r, &s, &c);
+    }
+};
+
+// ---- right-hand side ---------------------------------------------------------------------------
+// a  = [Re A1, Im A1, Re A2, ...]; (Er, Ei) = 2*gamma*exp(+i*dbeta*z) per sideband pair;
+// g  = gamma, tg = 2*gamma, ha = -alpha/2.   k = dA/dz.
+//
+//   dA_j/dz = (ha + i*gamma*f_j) A_j + i*conj(partner) * F      (yaman_model.py:123-186)
+//   f_j = P_j + 2*sum_{k!=j} P_k = 2*S - P_j
+//   pumps:     F = E * (A_s A_i)          (exp(+i dbeta z), yaman_model.py:174,177-178)
+//   sidebands: F = conj(E) * (A_p1 A_p2)  (exp(-i dbeta z), yaman_model.py:175,180-181)
+// 64 DP instructions for NW = 4.
+template <typename T, int NW>
+__device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(NW - 2) / 2],
+                                          const T (&Ei)[(NW - 2) / 2], const T g, const T tg, const T ha,
+                                          T (&k)[2 * NW]) {
+    constexpr int NP = (NW - 2) / 2;
+    T p[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) p[j] = fma_(a[2 * j], a[2 * j], a[2 * j + 1] * a[2 * j + 1]);
+    T s = (p[0] + p[1]) + (p[2] + p[3]);
+    if constexpr (NW == 6) s += (p[4] + p[5]);
+    const T gs = tg * s;  // gamma * 2S
+    T gj[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) gj[j] = fma_(-g, p[j], gs);  // gamma * f_j
+
+    const T x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3];
+    const T q12r = fma_(x1, x2, -(y1 * y2)), q12i = fma_(x1, y2, y1 * x2);  // A1*A2
+
+    T Fpr = T(0), Fpi = T(0);  // sum over pairs of E_p * (A_s A_i): drives both pumps
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+        const T xs = a[4 + 4 * pr], ys = a[5 + 4 * pr], xi = a[6 + 4 * pr], yi = a[7 + 4 * pr];
+        const T qr = fma_(xs, xi, -(ys * yi)), qi = fma_(xs, yi, ys * xi);  // A_s*A_i
+        if (pr == 0) {
+            Fpr = fma_(Er[pr], qr, -(Ei[pr] * qi));
+            Fpi = fma_(Er[pr], qi, Ei[pr] * qr);
+        } else {
+            Fpr = fma_(Er[pr], qr, fma_(-Ei[pr], qi, Fpr));
+            Fpi = fma_(Er[pr], qi, fma_(Ei[pr], qr, Fpi));
+        }
+        // conj(E_p) * (A1 A2): drives this pair's signal and idler
+        const T Fsr = fma_(Er[pr], q12r, Ei[pr] * q12i);
+        const T Fsi = fma_(Er[pr], q12i, -(Ei[pr] * q12r));
+        const T gS = gj[2 + 2 * pr], gI = gj[3 + 2 * pr];
+        // signal: (ha + i gS) A_s + i conj(A_i) Fs
+        k[4 + 4 * pr] = fma_(yi, Fsr, fma_(-xi, Fsi, fma_(-gS, ys, ha * xs)));
+        k[5 + 4 * pr] = fma_(xi, Fsr, fma_(yi, Fsi, fma_(gS, xs, ha * ys)));
+        // idler:  (ha + i gI) A_i + i conj(A_s) Fs
+        k[6 + 4 * pr] = fma_(ys, Fsr, fma_(-xs, Fsi, fma_(-gI, yi, ha * xi)));
+        k[7 + 4 * pr] = fma_(xs, Fsr, fma_(ys, Fsi, fma_(gI, xi, ha * yi)));
+    }
+    // pump1: (ha + i g1) A1 + i conj(A2) Fp ;  pump2: (ha + i g2) A2 + i conj(A1) Fp
+    k[0] = fma_(y2, Fpr, fma_(-x2, Fpi, fma_(-gj[0], y1, ha * x1)));
+    k[1] = fma_(x2, Fpr, fma_(y2, Fpi, fma_(gj[0], x1, ha * y1)));
+    k[2] = fma_(y1, Fpr, fma_(-x1, Fpi, fma_(-gj[1], y2, ha * x2)));
+    k[3] = fma_(x1, Fpr, fma_(y1, Fpi, fma_(gj[1], x2, ha * y2)));
+}
+
+// (Er,Ei) *= (rc,rs)
+template <typename T>
+__device__ __forceinline__ void rotate(T &Er, T &Ei, const T rc, const T rs) {
+    const T nr = fma_(Er, rc, -(Ei * rs));
+    const T ni = fma_(Er, rs, Ei * rc);
+    Er = nr;
+    Ei = ni;
+}
+
+// true iff any component is NaN/Inf: x*0 is NaN exactly for non-finite x.
+template <typename T, int NC>
+__device__ __forceinline__ bool any_nonfinite(const T (&y)[NC]) {
+    T t = T(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t = fma_(y[c], T(0), t);
+    return t != t;
+}
+
+// ---- the sweep kernel ------------------------------------------------------------------------------
+template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kernel(const SweepArgs<T> A) {
+    constexpr int NC = 2 * NW;
+    constexpr int NP = (NW - 2) / 2;
+    constexpr int RESYNC = Phase<T>::RESYNC;
+    const long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long N = A.n_points;
+    if (idx >= N) return;
+
+    // -- per-point inputs: one coalesced load per array (512 B per wave instruction in f64)
+    T y[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) y[c] = A.a0[(long long)c * A.a0_ld + idx * A.a0_stride];
+    const T g = A.gamma[idx * A.gamma_stride];
+    const T tg = g + g;
+    const T ha = T(-0.5) * A.alpha[idx * A.alpha_stride];
+    double dbd[NP];
+    dbd[0] = (double)A.dbeta[idx];
+    if constexpr (NP == 2) dbd[1] = (double)A.dbeta2[idx];
+
+    const double hd = A.z_max / (double)A.n_steps;  // np.linspace step
+    const T h = (T)hd, hh = (T)(0.5 * hd), h6 = (T)(hd / 6.0);
+
+    T rc[NP], rs[NP], Er[NP], Ei[NP];  // half-step rotator and the running 2*gamma*exp(i dbeta z)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        Phase<T>::eval(dbd[p] * (0.5 * hd), rc[p], rs[p]);
+        Er[p] = tg;
+        Ei[p] = T(0);
+    }
+
+    T pe = fma_(y[4], y[4], y[5] * y[5]);  // |A_sig|^2 at the last saved row (z = 0 is a saved row)
+    T pm = pe;                             // np.max over saved rows
+    long long bad = -1;
+
+    const int se = A.save_every;
+    const int n_rows = A.n_steps / se;                                 // saved rows after z = 0
+    const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;  // the tail only matters for check_nan
+
+    if constexpr (TRAJ) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) A.traj[(long long)c * N + idx] = y[c];
+    }
+    if (n_rows == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
+    }
+
+    int to_save = se;
+    int row = 0;
+    for (int i = 0; i < n_run; ++i) {
+        if ((i & (RESYNC - 1)) == 0) {  // wave-uniform: exact re-seed of the phase recurrence
+            const double z = (double)i * hd;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                T c, s;
+                Phase<T>::eval(dbd[p] * z, c, s);
+                Er[p] = tg * c;
+                Ei[p] = tg * s;
+            }
+        }
+        // ---- classic RK4 (integrators.py:54-59), low storage: y, y_stage, accumulator
+        T k[NC], ys[NC], acc[NC];
+        yaman_rhs<T, NW>(y, Er, Ei, g, tg, ha, k);  // k1 at z
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] = k[c];
+            ys[c] = fma_(hh, k[c], y[c]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h/2
+        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k2
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] = fma_(T(2), k[c], acc[c]);
+            ys[c] = fma_(hh, k[c], y[c]);
+        }
+        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k3
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] = fma_(T(2), k[c], acc[c]);
+            ys[c] = fma_(h, k[c], y[c]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h
+        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k4
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] = fma_(h6, acc[c] + k[c], y[c]);
+
+        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step
+            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i;
+        }
+        if (--to_save == 0) {  // (i + 1) % save_every == 0, integrators.py:137 -- wave-uniform
+            to_save = se;
+            ++row;
+            pe = fma_(y[4], y[4], y[5] * y[5]);
+            pm = (pe > pm || pe != pe) ? pe : pm;  // np.max propagates NaN
+            if constexpr (CHECK == CHECK_BLOCK) {
+                if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i;
+            }
+            if constexpr (TRAJ) {
+                T *dst = A.traj + (long long)row * NC * N + idx;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dst[(long long)c * N] = y[c];
+            }
+            if (row == n_rows) {  // A[-1]: the last saved row, not necessarily z_max (R8)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
+            }
+        }
+    }
+    if constexpr (CHECK == CHECK_BLOCK) {  // covers the unsaved tail
+        if (bad < 0 && n_run > 0 && any_nonfinite<T, NC>(y)) bad = n_run - 1;
+    }
+    A.p_end[idx] = pe;
+    A.p_max[idx] = pm;
+    A.first_bad[idx] = bad;
+}
+
+template <typename T, int NW, int CHECK, bool TRAJ>
+static hipError_t launch_one(hipStream_t s, int block, const SweepArgs<T> &a) {
+    if (a.n_points == 0) return hipSuccess;
+    if (block == 64) {
+        const unsigned grid = (unsigned)((a.n_points + 63) / 64);
+        hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 64>), dim3(grid), dim3(64), 0, s, a);
+    } else {
+        const unsigned grid = (unsigned)((a.n_points + 255) / 256);
+        hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 256>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <typename T, int NW>
+static hipError_t launch_nw(hipStream_t s, int check, int block, const SweepArgs<T> &a) {
+    const bool traj = a.traj != nullptr;
+    switch (check) {
+        case CHECK_NONE:
+            return traj ? launch_one<T, NW, CHECK_NONE, true>(s, block, a)
+                        : launch_one<T, NW, CHECK_NONE, false>(s, block, a);
+        case CHECK_BLOCK:
+            return traj ? launch_one<T, NW, CHECK_BLOCK, true>(s, block, a)
+                        : launch_one<T, NW, CHECK_BLOCK, false>(s, block, a);
+        default:
+            return traj ? launch_one<T, NW, CHECK_EXACT, true>(s, block, a)
+                        : launch_one<T, NW, CHECK_EXACT, false>(s, block, a);
+    }
+}
+
+template <typename T>
+static hipError_t launch_sweep_t(hipStream_t s, int n_waves, int check, bool /*lds*/, int block,
+                                 const SweepArgs<T> &a) {
+    if (n_waves == 4) return launch_nw<T, 4>(s, check, block, a);
+    return launch_nw<T, 6>(s, check, block, a);
+}
+
+}  // namespace psa

@@ -1,0 +1,11 @@
+"""Import alias: ``import psa_amd`` loads the package that lives in
+``psa-simulation-ode-rk-mvp-dispersion_amd/`` (a directory name Python cannot import directly)."""
+import importlib.util as _u
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "psa-simulation-ode-rk-mvp-dispersion_amd")
+_spec = _u.spec_from_file_location("psa_amd", _os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = _u.module_from_spec(_spec)
+_sys.modules["psa_amd"] = _mod
+_spec.loader.exec_module(_mod)

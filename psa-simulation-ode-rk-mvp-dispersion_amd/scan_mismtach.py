@@ -1,0 +1,271 @@
+"""Sweep drivers with the reference's call surface (the module keeps the upstream spelling ``scan_mismtach``).
+
+* ``plot_max_signal_gain_vs_lambda_signal(...) -> (x, gain_max)``            reference scan_mismtach.py:262-430
+* ``plot_max_gain_and_dbeta_vs_lambda_signal(...) -> (x, gain_max, dbeta)``  reference scan_mismtach.py:588-783
+* ``scan_dbeta_seeded_signal(...)``: a working direct-dbeta scan with gain_mode "end" | "max" and the
+  argmax-over-sweep summary -- what the reference's dead ``scan_mismatch_seeded_signal`` (:43-259) set out to do.
+
+Where the reference loops over lambda3 in Python and calls ``run_single_simulation`` per point, these drivers
+build every plan and every dbeta at once on the host (``plan_from_wavelengths_batch``,
+``compute_phase_mismatch_batch``), launch ONE HIP sweep over all valid points and reduce the gain on the GPU.
+
+Failure conventions kept from the reference: malformed arguments raise ``ValueError`` up front
+(:315-349, :630-671); anything that would raise INSIDE the per-point ``try`` (an impossible plan, a bad cfg,
+FloatingPointError from ``check_nan``) never raises -- the point's gain (and dbeta) is NaN (:391-392, :736-738).
+Plotting is presentation only: it happens after the numbers exist and only if matplotlib is importable.
+"""
+from __future__ import annotations
+
+from typing import Literal, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .config import SimulationConfig, custom_simulation_config, n_steps_of  # noqa: F401
+from .dispersion import DispersionParams
+from .frequency_plan import plan_from_wavelengths_batch
+from .phase_matching import PhaseMatchingConfig, PhaseMatchingMethod, compute_phase_mismatch_batch
+from .simulation import _prepare, make_initial_amplitudes
+from .sweep import SweepResult, rk4_sweep
+
+GainMode = Literal["end", "max"]
+
+
+def _select_power_metric(Pz: np.ndarray, mode: GainMode) -> float:
+    """P(z_max) ("end") or max_z P(z) ("max") of one power trace (scan_mismtach.py:27-40)."""
+    Pz = np.asarray(Pz)
+    if Pz.ndim != 1:
+        raise ValueError("Pz must be a 1D array of power versus z.")
+    if mode == "end":
+        return float(Pz[-1])
+    if mode == "max":
+        return float(np.max(Pz))
+    raise ValueError(f"Unknown gain_mode={mode!r}. Use 'end' or 'max'.")
+
+
+# ---- argument checks shared by the two lambda3 drivers ---------------------------------------------------
+def _check_sweep_inputs(lambda_signal_m, p_in, phase_in):
+    lam3 = np.asarray(list(lambda_signal_m), dtype=float)
+    if lam3.ndim != 1 or lam3.size == 0:
+        raise ValueError("lambda_signal_m must be a non-empty 1D sequence")
+    if not np.all(np.isfinite(lam3)) or np.any(lam3 <= 0.0):
+        raise ValueError("lambda_signal_m must contain finite positive wavelengths (m)")
+    p0 = np.asarray(list(p_in), dtype=float)
+    if p0.shape != (4,):
+        raise ValueError(f"p_in must have shape (4,), got {p0.shape}")
+    if not np.all(np.isfinite(p0)) or np.any(p0 < 0.0):
+        raise ValueError("p_in must contain finite non-negative powers")
+    if p0[2] <= 0.0:
+        raise ValueError("p_in[2] (signal seed power) must be > 0 to define gain")
+    ph0 = None
+    if phase_in is not None:
+        ph0 = np.asarray(list(phase_in), dtype=float)
+        if ph0.shape != (4,):
+            raise ValueError(f"phase_in must have shape (4,), got {ph0.shape}")
+        if not np.all(np.isfinite(ph0)):
+            raise ValueError("phase_in must contain finite values")
+    return lam3, p0, ph0
+
+
+def _norm_choice(value, name, allowed):
+    v = str(value).strip().lower()
+    if v not in allowed:
+        pretty = " or ".join(f"'{a}'" for a in allowed) if name != "gain_unit" else "'dB' or 'linear'"
+        raise ValueError(f"{name} must be {pretty}")
+    return v
+
+
+def _wavelength_axis(lam3, unit):
+    u = unit.strip().lower()
+    if u == "nm":
+        return lam3 * 1e9, r"Signal wavelength $\lambda_3$ (nm)"
+    if u == "m":
+        return lam3, r"Signal wavelength $\lambda_3$ (m)"
+    raise ValueError("return_wavelength_unit must be 'm' or 'nm'")
+
+
+# ---- the engine call shared by the drivers ------------------------------------------------------------------
+def _sweep_gain(*, cfg, lam1, lam2, lam3, gamma, alpha, p0, ph0, dispersion, pm_cfg, length_unit, gain_unit,
+                gain_mode="max", device=0):
+    """Everything the reference does inside its per-point ``try``, for all points at once.
+
+    Returns (gain[N], dbeta_m[N] per metre, SweepResult | None).  Never raises for per-point or cfg problems:
+    those become NaN, as ``except Exception`` does upstream.
+    """
+    N = lam3.size
+    gain = np.full(N, np.nan)
+    try:
+        # plan-independent part of run_single_simulation (validation, unit scaling, containers)
+        pre = _prepare(cfg, gamma=gamma, alpha=alpha, dispersion=dispersion, phase_matching_cfg=pm_cfg,
+                       beta_legacy=None, length_unit=length_unit)
+        a0 = make_initial_amplitudes(p0, ph0)
+        fiber, grid, pm = pre["fiber"], pre["grid"], pre["pm"].config
+        omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
+        dbeta_m, ok_db = compute_phase_mismatch_batch(omega, fiber.dispersion, pm)
+        ok &= ok_db
+        n_steps = n_steps_of(fiber.length_m, grid.dz_m)
+        if n_steps < 1:
+            raise ValueError("no steps")
+    except Exception:
+        return gain, np.full(N, np.nan), None
+    idx = np.flatnonzero(ok)
+    if idx.size == 0:
+        return gain, dbeta_m, None
+    res = rk4_sweep(dbeta_m[idx], z_max=fiber.length_m, n_steps=n_steps, save_every=cfg.save_every,
+                    check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m, a0=a0, device=device)
+    gain[idx] = res.gain(p0[2], mode=gain_mode, unit=gain_unit, device=device)
+    return gain, dbeta_m, res
+
+
+def _maybe_plot(draw, save_path, show):
+    """Presentation tail (scan_mismtach.py:412-428, :753-781); skipped when there is nothing to show or save."""
+    if save_path is None and not show:
+        return
+    try:
+        import matplotlib.pyplot as plt
+    except Exception:  # plotting is optional here
+        return
+    fig = draw(plt)
+    if save_path is not None:
+        fig.savefig(save_path, dpi=200, bbox_inches="tight")
+    if show:
+        plt.show()
+    else:
+        plt.close(fig)
+
+
+def plot_max_signal_gain_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: float,
+                                          lambda_signal_m: Sequence[float], gamma: float, alpha: float,
+                                          p_in: Sequence[float], phase_in: Optional[Sequence[float]] = None,
+                                          dispersion: Optional[DispersionParams] = None,
+                                          phase_matching_cfg: Optional[PhaseMatchingConfig] = None,
+                                          length_unit: str = "m", return_wavelength_unit: str = "nm",
+                                          gain_unit: str = "dB", xscale: str = "linear", yscale: str = "linear",
+                                          show_progress: bool = True, tqdm_desc: str = "Sweeping λ3",
+                                          save_path: Optional[str] = None, show: bool = True
+                                          ) -> Tuple[np.ndarray, np.ndarray]:
+    """Max-over-z signal gain versus lambda3 -> (x_wavelength, gain_max); NaN where a point failed.
+
+    ``show_progress`` / ``tqdm_desc`` are accepted for compatibility: the sweep is a single kernel launch.
+    """
+    lam1, lam2 = float(lambda_p1_m), float(lambda_p2_m)
+    lam3, p0, ph0 = _check_sweep_inputs(lambda_signal_m, p_in, phase_in)
+    unit = _norm_choice(gain_unit, "gain_unit", ("db", "linear"))
+    xs = _norm_choice(xscale, "xscale", ("linear", "log"))
+    ys = _norm_choice(yscale, "yscale", ("linear", "log"))
+    if ys == "log" and unit == "db":
+        raise ValueError("yscale='log' is not supported with gain_unit='dB'. Use gain_unit='linear'.")
+
+    gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
+                             dispersion=dispersion, pm_cfg=phase_matching_cfg, length_unit=length_unit,
+                             gain_unit=unit)
+    x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
+
+    def draw(plt):
+        fig = plt.figure()
+        plt.plot(x, gain, marker="o")
+        plt.xlabel(x_label)
+        plt.ylabel(r"Max signal gain $G_{\max}$ (linear)" if unit == "linear" else r"Max signal gain $G_{\max}$ (dB)")
+        plt.title("Maximum signal gain vs signal wavelength")
+        plt.grid(True, which="both")
+        plt.xscale(xs)
+        plt.yscale(ys)
+        return fig
+
+    _maybe_plot(draw, save_path, show)
+    return x, gain
+
+
+def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: float,
+                                             lambda_signal_m: Sequence[float], gamma: float, alpha: float,
+                                             p_in: Sequence[float], phase_in: Optional[Sequence[float]] = None,
+                                             dispersion: DispersionParams,
+                                             phase_matching_cfg: Optional[PhaseMatchingConfig] = None,
+                                             length_unit: str = "m", return_wavelength_unit: str = "nm",
+                                             gain_unit: str = "dB", xscale: str = "linear",
+                                             yscale_gain: str = "linear", yscale_dbeta: str = "linear",
+                                             show_progress: bool = True,
+                                             tqdm_desc: str = "Sweeping λ3 (gain + dBeta)",
+                                             save_path: Optional[str] = None, show: bool = True
+                                             ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """One sweep that returns both the max signal gain and dbeta(lambda3) -> (x, gain_max, dbeta).
+
+    ``dbeta`` is in 1/length_unit, computed from the dispersion AS GIVEN (scan_mismtach.py:700-706); the kernel
+    uses the per-metre value derived from the scaled dispersion (simulation.py:340), exactly as upstream.
+    """
+    lam1, lam2 = float(lambda_p1_m), float(lambda_p2_m)
+    lam3, p0, ph0 = _check_sweep_inputs(lambda_signal_m, p_in, phase_in)
+    if dispersion is None:
+        raise ValueError("dispersion must be provided to compute dBeta(λ3)")
+    unit = _norm_choice(gain_unit, "gain_unit", ("db", "linear"))
+    xs = _norm_choice(xscale, "xscale", ("linear", "log"))
+    ysg = _norm_choice(yscale_gain, "yscale_gain", ("linear", "log"))
+    ysd = _norm_choice(yscale_dbeta, "yscale_dbeta", ("linear", "log"))
+    if ysg == "log" and unit == "db":
+        raise ValueError("yscale_gain='log' is not supported with gain_unit='dB'. Use gain_unit='linear'.")
+    pm_cfg = phase_matching_cfg if phase_matching_cfg is not None else PhaseMatchingConfig(
+        method=PhaseMatchingMethod.SYMMETRIC_EVEN, max_order=4, even_orders=(2, 4), atol=0.0, rtol=1e-12)
+
+    # dbeta in the caller's units: per point, NaN where the plan or the mismatch is invalid
+    try:
+        omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
+        dbeta, ok_db = compute_phase_mismatch_batch(omega, dispersion, pm_cfg)
+        dbeta = np.where(ok & ok_db, dbeta, np.nan)
+    except Exception:
+        dbeta = np.full(lam3.shape, np.nan)
+
+    gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
+                             dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit)
+    gain = np.where(np.isnan(dbeta), np.nan, gain)   # a point whose dbeta failed never reaches the run upstream
+    x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
+    ref_line = -float(gamma) * float(p0[0] + p0[1])
+
+    def draw(plt):
+        fig, (ax1, ax2) = plt.subplots(2, 1, sharex=True, figsize=(9, 7))
+        ax1.plot(x, gain, marker="o")
+        ax1.set_ylabel("Max signal gain (linear)" if unit == "linear" else "Max signal gain (dB)")
+        ax1.grid(True, which="both", alpha=0.3)
+        ax1.set_yscale(ysg)
+        ax2.plot(x, dbeta, marker="o", label=r"$\Delta\beta(\lambda_3)$")
+        ax2.axhline(ref_line, ls="--", lw=2, label=r"$\gamma(P_1+P_2)$")
+        ax2.set_xlabel(x_label)
+        ax2.set_ylabel(rf"$\Delta\beta$  [1/{length_unit}]")
+        ax2.grid(True, which="both", alpha=0.3)
+        ax2.set_xscale(xs)
+        ax2.set_yscale(ysd)
+        ax2.legend()
+        fig.suptitle("Max signal gain and phase mismatch vs signal wavelength")
+        fig.tight_layout()
+        return fig
+
+    _maybe_plot(draw, save_path, show)
+    return x, gain, dbeta
+
+
+def scan_dbeta_seeded_signal(*, cfg: SimulationConfig, delta_beta: Sequence[float], gamma, alpha,
+                             p_in: Sequence[float], phase_in: Optional[Sequence[float]] = None,
+                             length_unit: str = "m", gain_mode: GainMode = "end", gain_unit: str = "dB",
+                             dtype=np.float64, device: int = 0) -> dict:
+    """Scan the phase mismatch directly (PROVIDED dbeta per point) and summarise the signal gain.
+
+    delta_beta: (N,) in 1/length_unit.  gamma / alpha: scalars or (N,) in per-length_unit.
+    Returns dict(delta_beta, gain, best_index, best_delta_beta, best_gain, n_finite, result=SweepResult,
+    points_per_s) -- gain with the reference's NaN rules, argmax/max reduced on the GPU.
+    """
+    if gain_mode not in ("end", "max"):
+        raise ValueError(f"Unknown gain_mode={gain_mode!r}. Use 'end' or 'max'.")
+    unit = _norm_choice(gain_unit, "gain_unit", ("db", "linear"))
+    db = np.asarray(delta_beta, dtype=float)
+    if db.ndim != 1 or db.size == 0:
+        raise ValueError("delta_beta must be a non-empty 1D sequence")
+    _, p0, ph0 = _check_sweep_inputs([1.0], p_in, phase_in)
+    pre = _prepare(cfg, gamma=0.0, alpha=0.0, dispersion=None,
+                   phase_matching_cfg=PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, provided_delta_beta=0.0),
+                   beta_legacy=None, length_unit=length_unit)
+    scale, L, dz_m = pre["scale"], pre["fiber"].length_m, pre["grid"].dz_m
+    res = rk4_sweep(db / scale, z_max=L, dz=dz_m, save_every=cfg.save_every, check_nan=bool(cfg.check_nan),
+                    gamma=np.asarray(gamma, dtype=float) / scale, alpha=np.asarray(alpha, dtype=float) / scale,
+                    a0=make_initial_amplitudes(p0, ph0), dtype=dtype, device=device)
+    gain, bi, bg, nf = res.summary(p0[2], mode=gain_mode, unit=unit, device=device)
+    secs = max(res.elapsed_ms, 1e-9) * 1e-3
+    return dict(delta_beta=db, gain=gain, best_index=bi, best_delta_beta=(float(db[bi]) if bi >= 0 else float("nan")),
+                best_gain=bg, n_finite=nf, result=res, points_per_s=db.size / secs)

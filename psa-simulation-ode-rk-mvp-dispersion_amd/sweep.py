@@ -1,0 +1,79 @@
+"""The batched engine behind the sweep drivers: N independent propagations in one kernel launch.
+
+The reference runs a sweep as a Python ``for`` over points, each calling ``run_single_simulation``
+(scan_mismtach.py:357-392, :694-738).  Here the per-point scalars become arrays (dbeta[N], optionally
+gamma[N], alpha[N], A0[N,4]) and the loop becomes the grid of ``psa_rk4_sweep_f64``: one sweep point per
+lane, the z-loop inside the kernel, only the summary (A_end, |A3|^2 at the last saved row, max over saved
+rows, first non-finite step) written back.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _native
+from .config import n_steps_of
+
+__all__ = ["SweepResult", "initial_amplitudes", "rk4_sweep"]
+
+
+def initial_amplitudes(p_in, phase_in=None) -> np.ndarray:
+    """A0 = sqrt(P) * exp(i*phi) for p_in (..., n_waves); the phase factor is skipped when every phase is 0
+    (simulation.py:120-123, so sqrt(P) stays bit-exact in the common seed-phase-zero case)."""
+    p = np.asarray(p_in, dtype=float)
+    amp = np.sqrt(p).astype(np.complex128)
+    if phase_in is not None:
+        ph = np.asarray(phase_in, dtype=float)
+        if np.any(ph != 0.0):
+            amp = amp * np.exp(1j * ph)
+    return amp
+
+
+@dataclass
+class SweepResult:
+    a_end: np.ndarray            # (N, n_waves) complex: state at the last SAVED row
+    p_end: np.ndarray            # (N,) |A_signal|^2 there
+    p_max: np.ndarray            # (N,) max over saved rows (z = 0 included), NaN-propagating
+    first_bad_step: np.ndarray   # (N,) int64, -1 = finite everywhere (or check_nan off)
+    n_steps: int
+    save_every: int
+    elapsed_ms: float            # kernel time (hipEvents)
+    traj: Optional[np.ndarray] = None   # (N, n_saved, n_waves) when requested
+
+    def gain(self, p0_sig: float, *, mode: str = "max", unit: str = "dB", device: int = 0) -> np.ndarray:
+        """Per-point signal gain with the drivers' NaN rules (scan_mismtach.py:376-392); reduced on the GPU."""
+        return self.summary(p0_sig, mode=mode, unit=unit, device=device)[0]
+
+    def summary(self, p0_sig: float, *, mode: str = "max", unit: str = "dB", device: int = 0):
+        """(gain[N], best_index, best_gain, n_finite) -- gain_mode "end" | "max" (scan_mismtach.py:27-40)."""
+        if mode not in ("end", "max"):
+            raise ValueError(f"Unknown gain_mode={mode!r}. Use 'end' or 'max'.")
+        u = str(unit).strip().lower()
+        if u not in ("db", "linear"):
+            raise ValueError("gain_unit must be 'dB' or 'linear'")
+        metric = self.p_max if mode == "max" else self.p_end
+        return _native.gain_summary_host(np.asarray(metric, dtype=np.float64), self.first_bad_step, float(p0_sig),
+                                         gain_db=(u == "db"), device=device)
+
+
+def rk4_sweep(dbeta, *, z_max: float, dz: Optional[float] = None, n_steps: Optional[int] = None,
+              save_every: int = 10, check_nan: bool = True, gamma, alpha, a0, dbeta2=None, dtype=np.float64,
+              device: int = 0, exact_step: bool = False, want_traj: bool = False) -> SweepResult:
+    """Propagate N points.  ``dz`` gives n = int(round(z_max/dz)) as integrators.py:194; or pass ``n_steps``."""
+    if z_max <= 0.0:
+        raise ValueError("z_max must be positive")
+    if n_steps is None:
+        if dz is None or dz <= 0.0:
+            raise ValueError("dz must be positive")
+        n_steps = n_steps_of(z_max, dz)
+    if save_every <= 0:
+        raise ValueError("save_every must be a positive integer")
+    if n_steps < 1:
+        raise ValueError("z_max / dz rounds to zero steps")
+    r = _native.sweep_host(dbeta, n_steps=int(n_steps), z_max=float(z_max), save_every=int(save_every), gamma=gamma,
+                           alpha=alpha, a0=a0, dbeta2=dbeta2, check_nan=check_nan, exact_step=exact_step,
+                           want_traj=want_traj, dtype=dtype, device=device)
+    return SweepResult(r["a_end"], r["p_end"], r["p_max"], r["first_bad_step"], int(n_steps), int(save_every),
+                       r["elapsed_ms"], r["traj"])

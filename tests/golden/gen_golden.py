@@ -262,7 +262,9 @@ def gen_g9():
     import config, scan_mismtach as sm
     p_in = np.array([0.5, 0.5, 1e-5, 1e-5])
     steps = []
-    gammas = np.array([50.0, 200.0, 1e3])
+    # 12.0 .. 10.29612 sit just past the RK4 stability edge (gamma*P*h ~ 1): the first bad step moves 2..5;
+    # 10.0 is stable (-1)
+    gammas = np.array([50.0, 200.0, 1e3, 12.0, 10.29664, 10.29613, 10.29612, 10.0])
     for g in gammas:
         try:
             _provided_run(100.0, 0.1, 10, 0.01, float(g), 0.0, p_in)

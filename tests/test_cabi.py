@@ -1,0 +1,103 @@
+"""The C-ABI library loads, exports every symbol include/psa_rk4.h declares, and validates arguments before
+touching a device (so these checks run without a GPU; no compute call is made here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import psa_amd._native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "psa_rk4.h")
+
+
+def _declared_symbols():
+    src = open(HEADER, encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(psa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = nat.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in psa_rk4.h but not exported"
+    assert sorted(nat.EXPORTED_SYMBOLS) == declared          # the ctypes table covers the whole header
+    assert nat.version().startswith("psa-hip") and "gfx950" in nat.version()
+    assert isinstance(nat.device_count(), int)
+
+
+def test_flag_values_match_the_header():
+    src = open(HEADER, encoding="utf-8").read()
+    for name, val in (("PSA_BCAST_GAMMA", nat.BCAST_GAMMA), ("PSA_BCAST_ALPHA", nat.BCAST_ALPHA),
+                      ("PSA_BCAST_A0", nat.BCAST_A0), ("PSA_OPT_CHECK_NAN", nat.OPT_CHECK_NAN),
+                      ("PSA_OPT_EXACT_STEP", nat.OPT_EXACT_STEP), ("PSA_OPT_LDS_STAGING", nat.OPT_LDS_STAGING),
+                      ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64)):
+        m = re.search(rf"#define\s+{name}\s+\(1u\s*<<\s*(\d+)\)", src)
+        assert m and (1 << int(m.group(1))) == val, name
+
+
+def test_n_saved_rule():
+    L = nat.lib()
+    assert L.psa_n_saved(1005, 10) == 101 and L.psa_n_saved(10, 2) == 6 and L.psa_n_saved(7, 10) == 1
+    assert L.psa_n_saved(10, 0) == -1
+
+
+def _call_dev(**over):
+    """psa_rk4_sweep_f64_dev with dummy non-NULL pointers; must fail in validation, before any launch."""
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    a = dict(n_waves=4, n_points=8, n_steps=10, z_max=1.0, save_every=1, dbeta2=None)
+    a.update(over)
+    return nat.lib().psa_rk4_sweep_f64_dev(None, a["n_waves"], a["n_points"], a["n_steps"], a["z_max"], a["save_every"],
+                                           p, a["dbeta2"], p, p, p, 0, p, p, p, p, None)
+
+
+@pytest.mark.parametrize("over,code", [(dict(n_waves=5), -1), (dict(n_points=-1), -2), (dict(n_steps=0), -3),
+                                       (dict(n_steps=2**31), -3), (dict(z_max=0.0), -4), (dict(z_max=float("nan")), -4),
+                                       (dict(save_every=0), -5), (dict(n_waves=6), -8)])
+def test_argument_errors_are_negative_codes_with_a_message(over, code):
+    assert _call_dev(**over) == code
+    assert len(nat.lib().psa_last_error()) > 0
+
+
+def test_null_pointer_and_dbeta2_rules():
+    L = nat.lib()
+    assert L.psa_rk4_sweep_f64_dev(None, 4, 8, 10, 1.0, 1, None, None, None, None, None, 0, None, None, None, None,
+                                   None) == -6
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert L.psa_rk4_sweep_f64_dev(None, 4, 8, 10, 1.0, 1, p, p, p, p, p, 0, p, p, p, p, None) == -8   # dbeta2 with 4 waves
+    # n_points == 0 is a valid no-op (empty sweep) on both faces, with or without a device
+    assert L.psa_rk4_sweep_f64_dev(None, 4, 0, 10, 1.0, 1, None, None, None, None, None, 0, None, None, None, None,
+                                   None) == 0
+    assert L.psa_rk4_sweep_f64(0, 4, 0, 10, 1.0, 1, None, None, None, None, None, 0, None, None, None, None, None,
+                               None) == 0
+    assert L.psa_yaman_rhs_f64(0, 0, None, None, None, None, None, None, None, None, None) == 0
+    assert L.psa_gain_summary_workspace_bytes(1000) > 0
+
+
+def test_python_wrapper_shape_checks():
+    a0 = np.ones(4, complex)
+    with pytest.raises(ValueError):
+        nat.sweep_host(np.zeros((2, 2)), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=a0)
+    with pytest.raises(ValueError):
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=[1.0, 2.0], alpha=0.0, a0=a0)
+    with pytest.raises(ValueError):
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=np.ones(5, complex))
+    with pytest.raises(ValueError):
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=np.ones(6, complex))
+    with pytest.raises(ValueError):
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=a0, dtype=np.float16)
+
+
+@pytest.mark.skipif(nat.device_count() > 0, reason="CPU box only")
+def test_host_entry_points_report_missing_device_not_a_fallback():
+    with pytest.raises(nat.PsaNativeError) as e:
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=np.ones(4, complex))
+    assert e.value.code == -7 and "no CPU fallback" in str(e.value)
+    with pytest.raises(nat.PsaNativeError):
+        nat.gain_summary_host(np.ones(4), None, 1.0)

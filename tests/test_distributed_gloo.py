@@ -1,0 +1,94 @@
+"""The N > 1 path on CPU: two processes, ``gloo`` backend, rendezvous on 127.0.0.1.
+
+The shard / pack / all_gather / unpack logic is what is under test; the local executor is injected (the CPU
+oracle), because the product executor is the HIP kernel and needs a GPU.  The result gathered by every rank must
+equal the unsharded run bit for bit, for even and ragged splits, per-point and broadcast arguments, and it must
+carry a failing point's first_bad_step through the float64 record unchanged.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_executor(dbeta, *, n_steps, z_max, save_every, gamma, alpha, a0, check_nan, dbeta2=None):
+    import oracle as O
+    return O.sweep(dbeta, z_max=z_max, n=n_steps, save_every=save_every, check_nan=check_nan, gamma=gamma,
+                   alpha=alpha, a0=a0, dbeta2=dbeta2, threads=1)
+
+
+def _worker(rank, world, port, n_points, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from psa_amd.distributed import sweep_sharded
+        rng = np.random.default_rng(11)
+        db = rng.uniform(-0.05, 0.05, n_points)
+        gam = rng.uniform(5e-3, 2e-2, n_points)
+        gam[n_points // 2] = 40.0                      # past the RK4 stability edge: the record must carry the index
+        a0 = np.sqrt(rng.uniform(1e-6, 1.0, (n_points, 4))) * np.exp(1j * rng.uniform(-3, 3, (n_points, 4)))
+        res = sweep_sharded(db, n_steps=300, z_max=30.0, save_every=7, gamma=gam, alpha=1e-4, a0=a0,
+                            executor=_oracle_executor)
+        res_b = sweep_sharded(db, n_steps=50, z_max=5.0, save_every=10, gamma=0.0115, alpha=0.0, a0=a0[0],
+                              executor=_oracle_executor)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), a_end=res.a_end, p_end=res.p_end, p_max=res.p_max,
+                 bad=res.first_bad_step, b_a_end=res_b.a_end, db=db, gam=gam, a0=a0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_points", [64, 37, 1])
+def test_two_rank_gloo_sweep_equals_unsharded(tmp_path, oracle, n_points):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_points, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for k in ("a_end", "p_end", "p_max", "bad", "b_a_end"):
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k        # every rank holds the full result
+    ref = oracle.sweep(r0["db"], z_max=30.0, n=300, save_every=7, gamma=r0["gam"], alpha=1e-4, a0=r0["a0"])
+    assert np.array_equal(r0["a_end"], ref["a_end"], equal_nan=True)
+    assert np.array_equal(r0["p_max"], ref["p_max"], equal_nan=True)
+    assert np.array_equal(r0["bad"], ref["first_bad_step"]) and r0["bad"].dtype == np.int64
+    if n_points > 1:
+        assert r0["bad"][n_points // 2] >= 0 and (np.delete(r0["bad"], n_points // 2) == -1).all()
+    ref_b = oracle.sweep(r0["db"], z_max=5.0, n=50, save_every=10, gamma=0.0115, alpha=0.0, a0=r0["a0"][0])
+    assert np.array_equal(r0["b_a_end"], ref_b["a_end"])
+
+
+def test_shard_bounds_partition():
+    from psa_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8, 65536, 1_048_577):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, w, r) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(1 << 20, 8, 3) == (3 * 131072, 4 * 131072)          # config 4: 131 072 points per GPU
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_record_roundtrip_keeps_int64_bits():
+    from psa_amd.distributed import pack_record, unpack_records
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(5, 4)) + 1j * rng.normal(size=(5, 4))
+    bad = np.array([-1, 0, 2**40 + 3, -1, 7], np.int64)
+    rec = pack_record(a, rng.normal(size=5), rng.normal(size=5), bad, 8)
+    assert rec.shape == (11, 8) and rec.nbytes == 88 * 8
+    a2, pe, pm, b2 = unpack_records(rec[None], 5, 1, 4)
+    assert np.array_equal(a2, a) and np.array_equal(b2, bad)

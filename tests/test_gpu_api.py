@@ -1,0 +1,183 @@
+"""GPU tests of the reference-shaped Python API (``-m gpu``): the same calls a user of the reference makes,
+served by the HIP kernels, compared with the outputs the reference itself produced (tests/golden)."""
+import numpy as np
+import pytest
+
+import psa_amd
+from psa_amd import config, dispersion, frequency_plan, integrators, parameters, scan_mismtach, simulation, yaman_model
+from psa_amd.phase_matching import PhaseMatchingConfig, PhaseMatchingMethod
+from conftest import ATOL_DB, RTOL_F64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _disp(g, prefix=""):
+    return dispersion.DispersionParams(omega_ref=float(g[prefix + "omega_ref"]), beta2=float(g[prefix + "beta2"]),
+                                       beta3=float(g[prefix + "beta3"]), beta4=float(g[prefix + "beta4"]))
+
+
+def test_g1_run_single_simulation_full_trajectory(golden):
+    """main.py:22-96 scenario through run_single_simulation: 10 000 steps, 1001 rows, 45.29 dB."""
+    g = golden("G1")
+    om = frequency_plan.plan_from_wavelengths(*g["lam"])
+    sp = frequency_plan.infer_symmetry_from_omegas(*om)
+    d = dispersion.dispersion_params_from_D_S(frequency_plan.lambda_from_omega(sp.omega_c), 0.02, 0.02, 0,
+                                              D_units="ps/nm/km", S_units="ps/nm^2/km", dSdlmbd_units="ps/nm^3/km",
+                                              omega_ref=sp.omega_c)
+    cfg = config.custom_simulation_config(z_max=1000.0, dz=0.1)
+    z, A = simulation.run_single_simulation(cfg, gamma=float(g["gamma"]), alpha=float(g["alpha"]), omega=om,
+                                            p_in=g["p_in"], phase_in=np.zeros(4), dispersion=d,
+                                            phase_matching_cfg=PhaseMatchingConfig(), length_unit="m")
+    assert A.shape == (1001, 4) and A.dtype == np.complex128
+    assert np.array_equal(z, g["z"])
+    assert rel_err(A, g["A"]) < RTOL_F64
+    gain = 10 * np.log10(abs(A[-1, 2]) ** 2 / g["p_in"][2])
+    assert abs(gain - 45.292443557977066) < ATOL_DB
+
+
+def test_g4_examples_km_path_and_wave_order(golden):
+    """reference tests.py:318 (example_zero_signal: A[0,2] == A[0,3] == 0 exactly) + both example trajectories."""
+    g = golden("G4")
+    z, A = simulation.example_zero_signal()
+    assert A.shape == g["zero_A"].shape and A[0, 2] == 0 and A[0, 3] == 0 and np.all(A[:, 2:] == 0)
+    np.testing.assert_allclose(z, g["zero_z"], rtol=0, atol=1e-15)
+    assert rel_err(A[:, :2], g["zero_A"][:, :2]) < RTOL_F64
+    z, A = simulation.custom_seeded_signal()
+    np.testing.assert_allclose(z, g["seeded_z"], rtol=0, atol=1e-15)
+    assert rel_err(A, g["seeded_A"]) < RTOL_F64
+
+
+def test_g2_gain_and_dbeta_driver(golden):
+    g = golden("G2")
+    cfg = config.custom_simulation_config(z_max=500.0, dz=0.2)
+    x, gain, db = scan_mismtach.plot_max_gain_and_dbeta_vs_lambda_signal(
+        cfg=cfg, lambda_p1_m=float(g["lambda_p1"]), lambda_p2_m=float(g["lambda_p2"]), lambda_signal_m=g["lambda3"],
+        gamma=float(g["gamma"]), alpha=float(g["alpha"]), p_in=g["p_in"], dispersion=_disp(g), length_unit="m",
+        gain_unit="dB", phase_in=np.zeros(4), show=False, show_progress=False)
+    assert np.array_equal(x, g["x"]) and np.array_equal(db, g["dbeta"])
+    np.testing.assert_allclose(gain, g["gain_db"], rtol=RTOL_F64, atol=ATOL_DB)
+    assert gain[0] == pytest.approx(9.6432746655328694e-16, rel=1e-6)      # floor points: max is the z = 0 row
+
+
+def test_g3_gain_driver_45_db(golden):
+    g = golden("G3")
+    cfg = config.custom_simulation_config(z_max=500.0, dz=0.2)
+    x, gain = scan_mismtach.plot_max_signal_gain_vs_lambda_signal(
+        cfg=cfg, lambda_p1_m=float(g["lambda_p1"]), lambda_p2_m=float(g["lambda_p2"]), lambda_signal_m=g["lambda3"],
+        gamma=float(g["gamma"]), alpha=float(g["alpha"]), p_in=g["p_in"], phase_in=np.zeros(4), dispersion=_disp(g),
+        phase_matching_cfg=PhaseMatchingConfig(), gain_unit="db", show=False, show_progress=False)
+    assert np.array_equal(x, g["x"]) and not np.isnan(gain).any()
+    np.testing.assert_allclose(gain, g["gain_db"], rtol=RTOL_F64, atol=ATOL_DB)
+    assert int(np.argmax(gain)) == 4
+
+
+def test_g11_km_units_linear_gain_input_phases(golden):
+    g = golden("G11")
+    for tag, unit in (("m", "m"), ("km", "km")):
+        z_max, dz, se, gamma, alpha = g[tag + "_cfg"]
+        dv = g["disp_" + tag]
+        d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3])
+        cfg = config.custom_simulation_config(z_max=z_max, dz=dz, save_every=int(se))
+        x, gain, db = scan_mismtach.plot_max_gain_and_dbeta_vs_lambda_signal(
+            cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1556e-9, lambda_signal_m=g["lambda3"], gamma=gamma, alpha=alpha,
+            p_in=g["p_in"], phase_in=g["phase_in"], dispersion=d, length_unit=unit, return_wavelength_unit="m",
+            gain_unit="linear", show=False, show_progress=False)
+        assert np.array_equal(x, g[tag + "_x"]) and np.array_equal(db, g[tag + "_dbeta"])
+        np.testing.assert_allclose(gain, g[tag + "_gain"], rtol=RTOL_F64)
+
+
+def test_g9_check_nan_raises_with_the_reference_step_index(golden):
+    g = golden("G9")
+    w0 = 2 * np.pi * 299792458.0 / 1.55e-6
+    pm = PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, provided_delta_beta=float(g["dbeta"]))
+    cfg = config.custom_simulation_config(z_max=100.0, dz=0.1)
+    for gam, step in zip(g["gammas"], g["first_bad_step"]):
+        kw = dict(gamma=float(gam), alpha=0.0, omega=np.full(4, w0), p_in=g["p_in"], phase_matching_cfg=pm)
+        if step >= 0:
+            with pytest.raises(FloatingPointError, match=rf"NaN or Inf detected at step {int(step)}, z = "):
+                simulation.run_single_simulation(cfg, **kw)
+        else:
+            z, A = simulation.run_single_simulation(cfg, **kw)
+            assert np.isfinite(A).all()
+    cfg_off = config.custom_simulation_config(z_max=100.0, dz=0.1, check_nan=False)
+    z, A = simulation.run_single_simulation(cfg_off, gamma=200.0, alpha=0.0, omega=np.full(4, w0), p_in=g["p_in"],
+                                            phase_matching_cfg=pm)
+    assert A.shape[0] == int(g["nocheck_n_rows"])
+    assert int(np.argmax(~np.isfinite(A).all(axis=1))) == int(g["nocheck_first_bad_row"])
+
+
+def test_g9_driver_nan_masks(golden):
+    g = golden("G9")
+    cfg = config.custom_simulation_config(z_max=100.0, dz=0.1)
+    d = _disp(g, "drv_")
+    x, gain = scan_mismtach.plot_max_signal_gain_vs_lambda_signal(
+        cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, lambda_signal_m=g["drv_lambda3"], gamma=200.0, alpha=0.0,
+        p_in=g["p_in"], dispersion=d, show=False, show_progress=False)
+    assert np.isnan(gain).all()                                   # every run overflows -> NaN, no exception
+    x, gain, db = scan_mismtach.plot_max_gain_and_dbeta_vs_lambda_signal(
+        cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, lambda_signal_m=g["mixed_lambda3"], gamma=0.0115, alpha=0.0,
+        p_in=g["p_in"], dispersion=d, show=False, show_progress=False)
+    np.testing.assert_array_equal(np.isnan(gain), [False, True, False])
+    np.testing.assert_allclose(gain[[0, 2]], g["mixed_gain"][[0, 2]], rtol=RTOL_F64, atol=ATOL_DB)
+    assert np.isnan(db[1]) and np.array_equal(db[[0, 2]], g["mixed_dbeta"][[0, 2]])
+
+
+def _params(gamma, alpha, dbeta):
+    mp = parameters.make_model_params(waves=parameters.WavesParams(omega=[1.2e15] * 4),
+                                      fiber=parameters.FiberParams(length_m=100.0, gamma_W_m=gamma, alpha_1_m=alpha),
+                                      grid=parameters.SimulationGrid(dz_m=0.1))
+    mp.cache.set_phase_mismatch(dbeta)
+    return mp
+
+
+def test_integrator_operator_api_with_the_native_handle(golden, oracle):
+    """integrate_interval / integrate_fixed_step / rk4_step accept ``rhs_yaman_simplified`` like the reference."""
+    g = golden("G7")
+    a0 = np.sqrt(g["p_in"]) * np.exp(1j * g["phase_in"])
+    mp = _params(float(g["gamma"]), float(g["alpha"]), float(g["dbeta"]))
+    z, A = integrators.integrate_interval(yaman_model.rhs_yaman_simplified, 100.5, 0.1, a0, mp, save_every=10)
+    assert np.array_equal(z, g["n1005_se10_z"]) and rel_err(A, g["n1005_se10_A"]) < RTOL_F64
+    z2, A2 = integrators.integrate_fixed_step(yaman_model.rhs_yaman_simplified, np.linspace(0, 100.5, 1006), a0, mp,
+                                              save_every=10)
+    assert np.array_equal(A2, A)
+    # one explicit step through the callable handle (4 launches of the batched RHS kernel)
+    y1 = integrators.rk4_step(yaman_model.rhs_yaman_simplified, 0.0, a0, 0.1, mp)
+    zr, Ar, _ = oracle.integrate(a0, z_max=0.1, n=1, save_every=1, gamma=float(g["gamma"]), alpha=float(g["alpha"]),
+                                 dbeta=float(g["dbeta"]))
+    assert rel_err(y1, Ar[-1]) < 1e-13
+    # a non-uniform grid cannot use the in-kernel z-loop: it goes through the callable contract, same numbers
+    grid = np.concatenate([np.linspace(0, 1.0, 11), [1.25, 1.5]])
+    z3, A3 = integrators.integrate_fixed_step(yaman_model.rhs_yaman_simplified, grid, a0, mp, save_every=1)
+    assert A3.shape == (13, 4) and np.isfinite(A3).all()
+
+
+def test_rhs_callable_matches_g5(golden):
+    g = golden("G5")
+    for i in range(0, 64, 7):
+        mp = _params(float(g["gamma"][i]), float(g["alpha"][i]), float(g["dbeta"][i]))
+        out = yaman_model.rhs_yaman_simplified(float(g["z"][i]), g["a"][i], mp)
+        assert out.shape == (4,) and out.dtype == np.complex128
+        assert np.max(np.abs(out - g["rhs"][i])) <= 1e-14 * np.max(np.abs(g["rhs"][i]))
+    with pytest.raises(ValueError, match="shape"):
+        yaman_model.rhs_yaman_simplified(0.0, np.ones(3, complex), _params(1.0, 0.0, 0.0))
+    lin, kerr, fwm = yaman_model.yaman_terms(g["z"], g["a"], g["gamma"], g["alpha"], g["dbeta"])
+    assert rel_err(kerr, g["kerr"]) < 1e-13
+
+
+def test_direct_dbeta_scan_end_and_max_modes(golden):
+    """The working counterpart of the reference's dead scan_mismatch_seeded_signal, pinned by G8."""
+    g = golden("G8")
+    cfg = config.custom_simulation_config(z_max=1000.0, dz=0.1)
+    for mode, key in (("end", "n1e4_a1_p_end"), ("max", "n1e4_a1_p_max")):
+        r = scan_mismtach.scan_dbeta_seeded_signal(cfg=cfg, delta_beta=g["dbeta257"], gamma=float(g["gamma"]),
+                                                   alpha=float(g["alphas"][1]), p_in=g["p_in"], gain_mode=mode,
+                                                   gain_unit="linear")
+        ref = g[key] / g["p_in"][2]
+        np.testing.assert_allclose(r["gain"], ref, rtol=RTOL_F64)
+        assert r["best_index"] == int(np.argmax(ref)) and r["n_finite"] == 257
+        assert r["best_delta_beta"] == g["dbeta257"][r["best_index"]]
+    # km units: dbeta, gamma, alpha x1000 and lengths /1000 give the same gains
+    cfg_km = config.custom_simulation_config(z_max=1.0, dz=1e-4)
+    rk = scan_mismtach.scan_dbeta_seeded_signal(cfg=cfg_km, delta_beta=g["dbeta257"] * 1e3, gamma=11.5, alpha=0.115,
+                                                p_in=g["p_in"], length_unit="km", gain_mode="max", gain_unit="linear")
+    np.testing.assert_allclose(rk["gain"], g["n1e4_a1_p_max"] / g["p_in"][2], rtol=1e-8)

@@ -1,0 +1,274 @@
+"""GPU parity tests (run on the MI355X box with ``-m gpu``).  Every call goes through the C-ABI of
+libpsa_hip.so; the checker is the CPU oracle (pinned by tests/test_oracle_golden.py) and the golden vectors
+produced by the reference itself.
+
+Tolerances (north-star: float64 within 1e-9 relative on final amplitudes and gain):
+  RTOL_F64 = 1e-9 elementwise on A_end / |A3|^2 / linear gain;  ATOL_DB = 5e-9 dB on gain in dB
+  (= 10*log10(1 + 1e-9)).  Measured agreement is ~1e-12.  float32: RTOL_F32 = 1e-3 (build-defined).
+"""
+import numpy as np
+import pytest
+
+import psa_amd._native as nat
+from conftest import ATOL_DB, RTOL_F32, RTOL_F64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+P_IN = np.array([0.5, 0.5, 1e-5, 1e-5])
+A0 = np.sqrt(P_IN).astype(complex)
+
+
+def _a0(p, ph=None):
+    a = np.sqrt(np.asarray(p, float)).astype(complex)
+    return a if ph is None or not np.any(np.asarray(ph) != 0) else a * np.exp(1j * np.asarray(ph))
+
+
+def test_native_library_is_the_one_in_tree_and_sees_the_gpu():
+    assert nat.LIB_PATH.endswith("psa-simulation-ode-rk-mvp-dispersion_amd/libpsa_hip.so")
+    assert nat.device_count() >= 1
+
+
+# ---- sweep kernel vs oracle: ragged sizes, strides, step counts ---------------------------------------------
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 257, 1000])
+@pytest.mark.parametrize("n,se", [(1000, 10), (1005, 10), (37, 1), (7, 10)])
+def test_sweep_matches_oracle_on_ragged_sizes(oracle, N, n, se):
+    rng = np.random.default_rng(100 * N + n)
+    db = rng.uniform(-0.1, 0.1, N)
+    ref = oracle.sweep(db, z_max=100.0, n=n, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    for flags in (0, nat.OPT_BLOCK64):
+        got = nat.sweep_host(db, n_steps=n, z_max=100.0, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0,
+                             check_nan=True, exact_step=True, extra_flags=flags)
+        assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
+        assert rel_err(got["p_end"], ref["p_end"]) < RTOL_F64
+        assert rel_err(got["p_max"], ref["p_max"]) < RTOL_F64
+        assert np.array_equal(got["first_bad_step"], ref["first_bad_step"])
+
+
+def test_per_point_gamma_alpha_a0_robustness_draw(oracle):
+    """SURVEY 8(d) robustness run: dbeta, gamma, pump powers, phases all per point (defeats value shortcuts)."""
+    rng = np.random.default_rng(2026)
+    N = 777
+    db = rng.uniform(-0.1, 0.1, N)
+    gamma = rng.uniform(5e-3, 2e-2, N)
+    alpha = rng.uniform(0.0, 3e-4, N)
+    alpha[::5] = 0.0
+    P = np.stack([rng.uniform(0.05, 1, N), rng.uniform(0.05, 1, N), 10 ** rng.uniform(-7, -4, N),
+                  10 ** rng.uniform(-7, -4, N)], 1)
+    a0 = np.sqrt(P) * np.exp(1j * rng.uniform(-np.pi, np.pi, (N, 4)))
+    ref = oracle.sweep(db, z_max=400.0, n=4000, save_every=10, gamma=gamma, alpha=alpha, a0=a0)
+    got = nat.sweep_host(db, n_steps=4000, z_max=400.0, save_every=10, gamma=gamma, alpha=alpha, a0=a0)
+    assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
+    assert rel_err(got["p_max"], ref["p_max"]) < RTOL_F64
+    assert (got["first_bad_step"] == -1).all()
+    # broadcast flags one at a time
+    for kw in (dict(gamma=0.0115), dict(alpha=1e-4), dict(a0=a0[3])):
+        args = dict(gamma=gamma, alpha=alpha, a0=a0)
+        args.update(kw)
+        ref = oracle.sweep(db, z_max=400.0, n=400, save_every=10, **args)
+        got = nat.sweep_host(db, n_steps=400, z_max=400.0, save_every=10, **args)
+        assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
+
+
+def test_empty_sweep_is_a_noop():
+    got = nat.sweep_host(np.zeros(0), n_steps=10, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=A0)
+    assert got["a_end"].shape == (0, 4) and got["p_max"].shape == (0,)
+
+
+# ---- golden fixtures (reference outputs) -------------------------------------------------------------------------
+@pytest.mark.parametrize("key,n,ai", [("n1e4_a0", 10_000, 0), ("n1e4_a1", 10_000, 1)])
+def test_g8_direct_dbeta_sweep(golden, key, n, ai):
+    g = golden("G8")
+    got = nat.sweep_host(g["dbeta257"], n_steps=n, z_max=1000.0, save_every=10, gamma=float(g["gamma"]),
+                         alpha=float(g["alphas"][ai]), a0=_a0(g["p_in"]))
+    assert rel_err(got["a_end"], g[key + "_A_end"]) < RTOL_F64
+    assert rel_err(got["p_end"], g[key + "_p_end"]) < RTOL_F64
+    assert rel_err(got["p_max"], g[key + "_p_max"]) < RTOL_F64
+
+
+def test_g8_1e5_steps(golden):
+    g = golden("G8")
+    got = nat.sweep_host(g["dbeta33"], n_steps=100_000, z_max=1000.0, save_every=10, gamma=float(g["gamma"]),
+                         alpha=float(g["alphas"][1]), a0=_a0(g["p_in"]))
+    assert rel_err(got["a_end"], g["n1e5_a1_A_end"]) < RTOL_F64
+    assert rel_err(got["p_max"], g["n1e5_a1_p_max"]) < RTOL_F64
+
+
+def test_g2_sweep_a_end_and_gain(golden):
+    g = golden("G2")
+    got = nat.sweep_host(g["dbeta"], n_steps=2500, z_max=500.0, save_every=10, gamma=float(g["gamma"]),
+                         alpha=float(g["alpha"]), a0=_a0(g["p_in"]))
+    assert rel_err(got["a_end"], g["A_end"]) < RTOL_F64
+    gain, bi, bg, nf = nat.gain_summary_host(got["p_max"], got["first_bad_step"], g["p_in"][2], gain_db=True)
+    np.testing.assert_allclose(gain, g["gain_db"], rtol=RTOL_F64, atol=ATOL_DB)
+    assert bi == int(np.argmax(g["gain_db"])) == 14 and nf == 30
+    assert bg == pytest.approx(7.6893941298573782, abs=ATOL_DB)
+
+
+def test_g5_rhs_kernel_and_terms(golden):
+    g = golden("G5")
+    out, lin, kerr, fwm = nat.yaman_rhs_host(g["z"], g["a"], g["gamma"], g["alpha"], g["dbeta"], terms=True)
+    for got, key in ((out, "rhs"), (lin, "linear"), (kerr, "kerr"), (fwm, "fwm")):
+        scale = np.max(np.abs(g[key]), axis=1, keepdims=True)
+        assert np.max(np.abs(got - g[key]) / np.maximum(scale, 1e-300)) < 1e-14, key
+
+
+def test_g7_trajectory_rows_and_stride_edges(golden):
+    g = golden("G7")
+    a0 = _a0(g["p_in"], g["phase_in"])
+    for tag in ("n1005_se10", "n1005_se1", "n3_se1", "n3_se2", "n7_se10"):
+        z_max, dz, se = g[tag + "_cfg"]
+        n = int(round(z_max / dz))
+        got = nat.sweep_host([float(g["dbeta"])], n_steps=n, z_max=z_max, save_every=int(se), gamma=float(g["gamma"]),
+                             alpha=float(g["alpha"]), a0=a0, want_traj=True, exact_step=True)
+        ref = g[tag + "_A"]
+        assert got["traj"].shape == (1,) + ref.shape, tag
+        assert rel_err(got["traj"][0], ref) < RTOL_F64, tag
+        assert rel_err(got["a_end"][0], ref[-1]) < RTOL_F64, tag     # A[-1] = last SAVED row
+
+
+def test_trajectory_layout_for_many_points(oracle):
+    """N > 1 exercises the SoA [row][comp][N] -> AoS [N][row][wave] transpose kernel (ragged N, rows*comps % 64 != 0)."""
+    N, n, se = 130, 205, 4
+    db = np.linspace(-0.05, 0.05, N)
+    got = nat.sweep_host(db, n_steps=n, z_max=50.0, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0, want_traj=True)
+    assert got["traj"].shape == (N, n // se + 1, 4)
+    for i in (0, 1, 63, 64, 129):
+        z, A, _ = oracle.integrate(A0, z_max=50.0, n=n, save_every=se, gamma=0.0115, alpha=1.15e-4, dbeta=db[i])
+        assert rel_err(got["traj"][i], A) < RTOL_F64
+    assert np.array_equal(got["traj"][:, -1, :], got["a_end"])
+    assert np.array_equal(np.abs(got["traj"][:, :, 2]).max(axis=1) ** 2 > 0, np.ones(N, bool))
+
+
+# ---- failure path -------------------------------------------------------------------------------------------------
+def test_g9_first_bad_step_exact_and_block_modes(golden):
+    g = golden("G9")
+    a0 = _a0(g["p_in"])
+    gam = g["gammas"]
+    db = np.full(gam.size, float(g["dbeta"]))
+    exact = nat.sweep_host(db, n_steps=1000, z_max=100.0, save_every=10, gamma=gam, alpha=0.0, a0=a0, check_nan=True,
+                           exact_step=True)
+    assert np.array_equal(exact["first_bad_step"], g["first_bad_step"])
+    block = nat.sweep_host(db, n_steps=1000, z_max=100.0, save_every=10, gamma=gam, alpha=0.0, a0=a0, check_nan=True,
+                           exact_step=False)
+    want = np.where(g["first_bad_step"] >= 0, 9, -1)          # last step of the first bad save block
+    assert np.array_equal(block["first_bad_step"], want)
+    off = nat.sweep_host(db, n_steps=1000, z_max=100.0, save_every=10, gamma=gam, alpha=0.0, a0=a0, check_nan=False)
+    assert (off["first_bad_step"] == -1).all()
+    failed = g["first_bad_step"] >= 0
+    assert np.isnan(off["p_max"][failed]).all() and np.isfinite(off["p_max"][~failed]).all()
+    gain, bi, bg, nf = nat.gain_summary_host(block["p_max"], block["first_bad_step"], g["p_in"][2])
+    assert np.array_equal(np.isnan(gain), failed) and nf == int((~failed).sum()) and bi == int(np.flatnonzero(~failed)[0])
+
+
+def test_failure_in_the_unsaved_tail_is_seen_only_with_check_nan(oracle):
+    """n = 4 < save_every = 10: no row is ever saved after z = 0, so the blow-up at step 2 (gamma = 12, h = 0.1, as in
+    G9) lies in the unsaved tail; check_nan must still report it, and A[-1] stays the input."""
+    ref = oracle.sweep(np.array([0.01]), z_max=0.4, n=4, save_every=10, gamma=12.0, alpha=0.0, a0=A0)
+    assert ref["first_bad_step"][0] == 2
+    got = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=True,
+                         exact_step=True)
+    assert got["first_bad_step"][0] == 2
+    assert np.array_equal(got["a_end"][0], A0) and got["p_max"][0] == got["p_end"][0] == abs(A0[2]) ** 2
+    blk = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=True)
+    assert blk["first_bad_step"][0] == 3                      # block mode: last step of the (partial) block
+    off = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=False)
+    assert off["first_bad_step"][0] == -1 and np.isfinite(off["p_max"][0])
+
+
+# ---- gain summary kernel ----------------------------------------------------------------------------------------------
+def test_gain_summary_reduction_matches_numpy():
+    rng = np.random.default_rng(5)
+    for N in (1, 64, 300, 70_001):
+        p = 10 ** rng.uniform(-9, -2, N)
+        bad = np.full(N, -1, np.int64)
+        p[rng.integers(0, N, max(1, N // 50))] = np.nan
+        p[rng.integers(0, N, max(1, N // 50))] = np.inf
+        p[rng.integers(0, N, max(1, N // 50))] = 0.0
+        bad[rng.integers(0, N, max(1, N // 50))] = 7
+        for db in (True, False):
+            gain, bi, bg, nf = nat.gain_summary_host(p, bad, 1e-7, gain_db=db)
+            with np.errstate(all="ignore"):
+                g = p / 1e-7
+                ok = np.isfinite(p) & np.isfinite(g) & (g > 0) & (bad < 0)
+                ref = np.where(ok, 10 * np.log10(np.where(ok, g, 1.0)) if db else g, np.nan)
+            np.testing.assert_allclose(gain, ref, rtol=1e-14, equal_nan=True)
+            assert nf == int(ok.sum())
+            if ok.any():
+                assert bi == int(np.nanargmax(ref)) and bg == pytest.approx(np.nanmax(ref), rel=1e-14)
+            else:
+                assert bi == -1 and np.isnan(bg)
+    gain, bi, bg, nf = nat.gain_summary_host(np.array([np.nan, np.nan]), None, 1.0)
+    assert bi == -1 and nf == 0 and np.isnan(bg)
+
+
+# ---- float32 and 6-wave variants (build-defined extensions) -----------------------------------------------------
+def test_float32_variant_within_build_defined_tolerance(oracle):
+    db = np.linspace(-0.05, 0.05, 513)
+    ref = oracle.sweep(db, z_max=1000.0, n=10_000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    got = nat.sweep_host(db, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0,
+                         dtype=np.float32, want_traj=False)
+    assert got["a_end"].dtype == np.complex64
+    assert rel_err(got["a_end"].astype(complex), ref["a_end"]) < RTOL_F32
+    assert rel_err(got["p_max"].astype(float), ref["p_max"]) < RTOL_F32
+    gd = 10 * np.log10(got["p_max"].astype(float) / 1e-5) - 10 * np.log10(ref["p_max"] / 1e-5)
+    assert np.max(np.abs(gd)) < 2e-3                             # dB
+
+
+def test_six_wave_kernel_vs_oracle_and_reduction(oracle):
+    """6-wave RHS is build-defined ("parity unpinned" vs the reference, which has none): the kernel must match the
+    oracle's statement of the same equations, and reduce to the 4-wave system when pair 2 is dark."""
+    db = np.linspace(-0.04, 0.04, 129)
+    db2 = 0.6 * db + 0.003
+    a06 = np.sqrt(np.array([0.5, 0.4, 1e-5, 1e-5, 3e-5, 2e-6])) * np.exp(1j * np.array([0.0, 0.3, 0.1, -0.2, 0.5, 1.0]))
+    ref = oracle.sweep(db, z_max=600.0, n=6000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a06, dbeta2=db2)
+    got = nat.sweep_host(db, n_steps=6000, z_max=600.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a06, dbeta2=db2)
+    assert got["a_end"].shape == (129, 6)
+    assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64 and rel_err(got["p_max"], ref["p_max"]) < RTOL_F64
+    dark = np.concatenate([A0, [0, 0]])
+    got6 = nat.sweep_host(db, n_steps=6000, z_max=600.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=dark, dbeta2=db2)
+    got4 = nat.sweep_host(db, n_steps=6000, z_max=600.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    assert rel_err(got6["a_end"][:, :4], got4["a_end"]) < 1e-12 and np.all(got6["a_end"][:, 4:] == 0)
+
+
+# ---- BASELINE.json full sizes: size-independent properties + sampled oracle check -------------------------------------
+def _c2_inputs(N=65536):
+    return np.linspace(-0.05, 0.05, N)
+
+
+def test_full_size_c2_properties_and_sampled_parity(oracle):
+    """Config 2: 65 536 points x 100 000 steps, fp64.  (i) 64 randomly sampled points against the oracle at full
+    length; (ii) power balance sum_j |A_j|^2 (L) = sum_j |A_j|^2 (0) * exp(-alpha L) (exact for the ODE, RK4 keeps
+    it to ~1e-12 here); (iii) Manley-Rowe: |A3|^2 - |A4|^2 follows the same decay; (iv) two shards == one launch,
+    bit for bit; (v) rerun is bit-identical."""
+    N, n, L, alpha = 65536, 100_000, 1000.0, 1.15e-4
+    db = _c2_inputs(N)
+    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=A0, check_nan=True)
+    assert (got["first_bad_step"] == -1).all()
+    pick = np.random.default_rng(65536).choice(N, 64, replace=False)
+    ref = oracle.sweep(db[pick], z_max=L, n=n, save_every=10, gamma=0.0115, alpha=alpha, a0=A0)
+    assert rel_err(got["a_end"][pick], ref["a_end"]) < RTOL_F64
+    assert rel_err(got["p_max"][pick], ref["p_max"]) < RTOL_F64
+    P = np.abs(got["a_end"]) ** 2
+    np.testing.assert_allclose(P.sum(1), P_IN.sum() * np.exp(-alpha * L), rtol=1e-10)
+    np.testing.assert_allclose(P[:, 2] - P[:, 3], (P_IN[2] - P_IN[3]) * np.exp(-alpha * L), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(P[:, 0] - P[:, 1], 0.0, atol=1e-12)
+    assert np.all(got["p_max"] >= got["p_end"]) and np.all(got["p_max"] >= P_IN[2] * (1 - 1e-15))
+    h = N // 2
+    lo = nat.sweep_host(db[:h], n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=A0)
+    hi = nat.sweep_host(db[h:], n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=A0)
+    assert np.array_equal(np.concatenate([lo["a_end"], hi["a_end"]]), got["a_end"])
+    assert np.array_equal(np.concatenate([lo["p_max"], hi["p_max"]]), got["p_max"])
+
+
+def test_full_size_c3_grid_sampled_parity(oracle):
+    """Config 3 shape: 1 048 576 points x 100 000 steps (about one second of GPU time); sampled oracle check."""
+    N, n, L, alpha = 1 << 20, 100_000, 1000.0, 1.15e-4
+    rng = np.random.default_rng(3)
+    db = rng.uniform(-0.02, 0.02, N)
+    a0 = _a0([0.1, 0.1, 1e-7, 1e-7])
+    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=a0, check_nan=True)
+    pick = rng.choice(N, 48, replace=False)
+    ref = oracle.sweep(db[pick], z_max=L, n=n, save_every=10, gamma=0.0115, alpha=alpha, a0=a0)
+    assert rel_err(got["a_end"][pick], ref["a_end"]) < RTOL_F64
+    P = np.abs(got["a_end"]) ** 2
+    np.testing.assert_allclose(P.sum(1), 0.2000002 * np.exp(-alpha * L), rtol=1e-10)

@@ -57,6 +57,7 @@ def cpu_baseline(target_seconds: float = 12.0) -> dict:
     import oracle as O
     a0 = np.sqrt(P_IN).astype(complex)
     cores = O.max_threads()
+    O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)  # warm
     t = time.perf_counter()
     O.sweep(np.linspace(*DBETA_RANGE, cores), z_max=Z_MAX, n=N_ZSTEPS // 10, save_every=SAVE_EVERY, gamma=GAMMA,
             alpha=ALPHA, a0=a0, threads=cores)

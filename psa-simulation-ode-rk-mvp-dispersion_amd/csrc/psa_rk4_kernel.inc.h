@@ -117,8 +117,12 @@ __device__ __forceinline__ bool any_nonfinite(const T (&y)[NC]) {
 }
 
 // ---- the sweep kernel ------------------------------------------------------------------------------
-template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kernel(const SweepArgs<T> A) {
+// LDS = true is the layout the north-star sketches (state and k1..k4 staged in LDS, [component][lane] so a wave's
+// ds_read/ds_write_b64 touches 64 consecutive 8-byte words: conflict-free).  It exists for the A/B in DESIGN.md
+// section 5: the register-resident form wins because the LDS round trips buy nothing (no data is shared
+// between lanes) and cost issue slots next to an already saturated FP64 pipe.
+template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK, bool LDS = false>
+__global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) {
     constexpr int NC = 2 * NW;
     constexpr int NP = (NW - 2) / 2;
     constexpr int RESYNC = Phase<T>::RESYNC;
@@ -165,20 +169,48 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kerne
         for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
     }
 
-    int to_save = se;
-    int row = 0;
-    for (int i = 0; i < n_run; ++i) {
-        if ((i & (RESYNC - 1)) == 0) {  // wave-uniform: exact re-seed of the phase recurrence
-            const double z = (double)i * hd;
+    // LDS-staged variant: sm_k[stage][component][lane] and sm_y[component][lane] (volatile: the traffic is the point)
+    __shared__ T sm_store[LDS ? 5 * NC * BLOCK : 1];
+    volatile T *sm_y = sm_store + threadIdx.x;
+    volatile T *sm_k = sm_store + NC * BLOCK + threadIdx.x;
+    if constexpr (LDS) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                T c, s;
-                Phase<T>::eval(dbd[p] * z, c, s);
-                Er[p] = tg * c;
-                Ei[p] = tg * s;
+        for (int c = 0; c < NC; ++c) sm_y[c * BLOCK] = y[c];
+    }
+    auto rk4_step_lds = [&](const int step_index) {
+        T k[NC], ys[NC];
+        const T coef[3] = {hh, hh, h};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ys[c] = sm_y[c * BLOCK];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sm_k[(st * NC + c) * BLOCK] = k[c];
+            if (st == 0 || st == 2) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);
+            }
+            if (st < 3) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ys[c] = fma_(coef[st], (T)sm_k[(st * NC + c) * BLOCK], (T)sm_y[c * BLOCK]);
             }
         }
-        // ---- classic RK4 (integrators.py:54-59), low storage: y, y_stage, accumulator
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const T k1 = sm_k[(0 * NC + c) * BLOCK], k2 = sm_k[(1 * NC + c) * BLOCK];
+            const T k3 = sm_k[(2 * NC + c) * BLOCK], k4 = sm_k[(3 * NC + c) * BLOCK];
+            y[c] = fma_(h6, fma_(T(2), k3, fma_(T(2), k2, k1)) + k4, (T)sm_y[c * BLOCK]);
+            sm_y[c * BLOCK] = y[c];
+        }
+        if constexpr (CHECK == CHECK_EXACT) {
+            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
+        }
+    };
+
+    // ---- one classic RK4 step (integrators.py:54-59), low storage: y, y_stage, accumulator.
+    // On entry (Er,Ei) = 2*gamma*exp(i*dbeta*z_step); on exit it has been rotated to z_step + h.
+    auto rk4_step_reg = [&](const int step_index) {
         T k[NC], ys[NC], acc[NC];
         yaman_rhs<T, NW>(y, Er, Ei, g, tg, ha, k);  // k1 at z
 #pragma unroll
@@ -205,17 +237,53 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kerne
         yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k4
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(h6, acc[c] + k[c], y[c]);
-
-        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step
-            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i;
+        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step (a select, not a branch)
+            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
         }
-        if (--to_save == 0) {  // (i + 1) % save_every == 0, integrators.py:137 -- wave-uniform
-            to_save = se;
+    };
+
+    // ---- z-loop, event driven: the steps between two events (a saved row, a phase re-seed, the end) run in a
+    // branch-free 2x-unrolled inner loop.  With one wave per SIMD (65 536 points fill the chip exactly once) every
+    // taken branch is an exposed instruction refetch, so per-step `if`s cost ~6 % -- see DESIGN.md section 5.
+    constexpr int CHUNK = RESYNC / 2;
+    int i = 0;
+    int since_seed = RESYNC;           // forces the seed at i = 0
+    int row = 0;
+    int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    while (i < n_run) {
+        if (since_seed >= CHUNK) {     // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
+            const double z = (double)i * hd;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                T c, s;
+                Phase<T>::eval(dbd[p] * z, c, s);
+                Er[p] = tg * c;
+                Ei[p] = tg * s;
+            }
+            since_seed = 0;
+        }
+        int end = i + CHUNK;
+        end = end < n_run ? end : n_run;
+        end = end < next_save ? end : next_save;
+        const int m = end - i;
+        int j = 0;
+        if constexpr (LDS) {
+            for (; j < m; ++j) rk4_step_lds(i + j);
+        } else {
+            for (; j + 2 <= m; j += 2) {
+                rk4_step_reg(i + j);
+                rk4_step_reg(i + j + 1);
+            }
+            if (j < m) rk4_step_reg(i + j);
+        }
+        i = end;
+        since_seed += m;
+        if (i == next_save) {  // (i % save_every == 0), integrators.py:137 -- wave-uniform
             ++row;
             pe = fma_(y[4], y[4], y[5] * y[5]);
             pm = (pe > pm || pe != pe) ? pe : pm;  // np.max propagates NaN
             if constexpr (CHECK == CHECK_BLOCK) {
-                if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i;
+                if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i - 1;
             }
             if constexpr (TRAJ) {
                 T *dst = A.traj + (long long)row * NC * N + idx;
@@ -225,6 +293,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kerne
             if (row == n_rows) {  // A[-1]: the last saved row, not necessarily z_max (R8)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
+                next_save = 0x7fffffff;
+            } else {
+                next_save += se;
             }
         }
     }
@@ -237,8 +308,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK >= 256 ? 4 : 1)) rk4_sweep_kerne
 }
 
 template <typename T, int NW, int CHECK, bool TRAJ>
-static hipError_t launch_one(hipStream_t s, int block, const SweepArgs<T> &a) {
+static hipError_t launch_one(hipStream_t s, int block, bool lds, const SweepArgs<T> &a) {
     if (a.n_points == 0) return hipSuccess;
+    if (lds) {  // A/B variant: one wave per workgroup, 5 * 2*NW * 64 * sizeof(T) bytes of LDS (20 KB for f64, 4 waves)
+        const unsigned grid = (unsigned)((a.n_points + 63) / 64);
+        hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 64, true>), dim3(grid), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if (block == 64) {
         const unsigned grid = (unsigned)((a.n_points + 63) / 64);
         hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 64>), dim3(grid), dim3(64), 0, s, a);
@@ -250,26 +326,26 @@ static hipError_t launch_one(hipStream_t s, int block, const SweepArgs<T> &a) {
 }
 
 template <typename T, int NW>
-static hipError_t launch_nw(hipStream_t s, int check, int block, const SweepArgs<T> &a) {
+static hipError_t launch_nw(hipStream_t s, int check, int block, bool lds, const SweepArgs<T> &a) {
     const bool traj = a.traj != nullptr;
     switch (check) {
         case CHECK_NONE:
-            return traj ? launch_one<T, NW, CHECK_NONE, true>(s, block, a)
-                        : launch_one<T, NW, CHECK_NONE, false>(s, block, a);
+            return traj ? launch_one<T, NW, CHECK_NONE, true>(s, block, lds, a)
+                        : launch_one<T, NW, CHECK_NONE, false>(s, block, lds, a);
         case CHECK_BLOCK:
-            return traj ? launch_one<T, NW, CHECK_BLOCK, true>(s, block, a)
-                        : launch_one<T, NW, CHECK_BLOCK, false>(s, block, a);
+            return traj ? launch_one<T, NW, CHECK_BLOCK, true>(s, block, lds, a)
+                        : launch_one<T, NW, CHECK_BLOCK, false>(s, block, lds, a);
         default:
-            return traj ? launch_one<T, NW, CHECK_EXACT, true>(s, block, a)
-                        : launch_one<T, NW, CHECK_EXACT, false>(s, block, a);
+            return traj ? launch_one<T, NW, CHECK_EXACT, true>(s, block, lds, a)
+                        : launch_one<T, NW, CHECK_EXACT, false>(s, block, lds, a);
     }
 }
 
 template <typename T>
-static hipError_t launch_sweep_t(hipStream_t s, int n_waves, int check, bool /*lds*/, int block,
+static hipError_t launch_sweep_t(hipStream_t s, int n_waves, int check, bool lds, int block,
                                  const SweepArgs<T> &a) {
-    if (n_waves == 4) return launch_nw<T, 4>(s, check, block, a);
-    return launch_nw<T, 6>(s, check, block, a);
+    if (n_waves == 4) return launch_nw<T, 4>(s, check, block, lds, a);
+    return launch_nw<T, 6>(s, check, block, lds, a);
 }
 
 }  // namespace psa

@@ -69,6 +69,22 @@ def test_per_point_gamma_alpha_a0_robustness_draw(oracle):
         assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
 
 
+def test_lds_staged_variant_matches_register_variant(oracle):
+    """PSA_OPT_LDS_STAGING (state + k1..k4 through LDS, the north-star's sketch) is numerically the same algorithm."""
+    db = np.linspace(-0.05, 0.05, 300)
+    ref = oracle.sweep(db, z_max=300.0, n=3000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    reg = nat.sweep_host(db, n_steps=3000, z_max=300.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    lds = nat.sweep_host(db, n_steps=3000, z_max=300.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0,
+                         extra_flags=nat.OPT_LDS_STAGING, exact_step=True)
+    assert rel_err(lds["a_end"], ref["a_end"]) < RTOL_F64 and rel_err(lds["p_max"], ref["p_max"]) < RTOL_F64
+    assert rel_err(lds["a_end"], reg["a_end"]) < 1e-12
+    a06 = np.concatenate([A0, np.sqrt([2e-5, 1e-6])])
+    r6 = oracle.sweep(db, z_max=100.0, n=1000, save_every=10, gamma=0.0115, alpha=0.0, a0=a06, dbeta2=-db)
+    l6 = nat.sweep_host(db, n_steps=1000, z_max=100.0, save_every=10, gamma=0.0115, alpha=0.0, a0=a06, dbeta2=-db,
+                        extra_flags=nat.OPT_LDS_STAGING)
+    assert rel_err(l6["a_end"], r6["a_end"]) < RTOL_F64
+
+
 def test_empty_sweep_is_a_noop():
     got = nat.sweep_host(np.zeros(0), n_steps=10, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=A0)
     assert got["a_end"].shape == (0, 4) and got["p_max"].shape == (0,)

@@ -66,6 +66,12 @@ def parity():
 
 def timing(big):
     a0 = np.sqrt(np.array([0.5, 0.5, 1e-5, 1e-5])).astype(complex)
+    for N in (65536, 1048576):   # register-resident vs LDS-staged (A/B of DESIGN.md section 5)
+        db = np.linspace(-0.05, 0.05, N)
+        for name, fl in (("registers/256", 0), ("registers/64", nat.OPT_BLOCK64), ("LDS-staged/64", nat.OPT_LDS_STAGING)):
+            best = min(nat.sweep_host(db, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4,
+                                      a0=a0, extra_flags=fl)["elapsed_ms"] for _ in range(3))
+            print(f"A/B N={N} n=10000 {name}: {best:.2f} ms -> {N * 1e4 / best / 1e6:.2f} G steps/s", flush=True)
     for N in (65536, 262144) + ((1048576,) if big else ()):
         db = np.linspace(-0.05, 0.05, N)
         for n in ((10_000, 100_000) if N == 65536 else (10_000,)):

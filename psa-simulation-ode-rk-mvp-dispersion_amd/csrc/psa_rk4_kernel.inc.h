@@ -8,7 +8,7 @@
 // What bounds it: FP64 vector FMA issue (16 lanes/clk/SIMD on CDNA4), NOT HBM and not MFMA:
 // a point reads 8..88 B and writes 88 B for its entire z-loop, and the RHS is an elementwise
 // complex polynomial (no contraction to tile).  So the design rules here are
-//   * minimum DP instructions per step (320 for 4 waves; see the count in DESIGN.md),
+//   * minimum DP instructions per step (298 for 4 waves; see the count in DESIGN.md),
 //   * no transcendental in the steady-state loop: E(z) = 2*gamma*exp(i*dbeta*z) is carried by a
 //     complex rotation per half step and re-seeded from an exact sincos every RESYNC steps
 //     (bounds the recurrence drift at ~1e-14, far inside the 1e-9 parity budget),
@@ -41,29 +41,34 @@ template <> struct Phase<float> {
     }
 };
 
-// ---- right-hand side ---------------------------------------------------------------------------
-// a  = [Re A1, Im A1, Re A2, ...]; (Er, Ei) = 2*gamma*exp(+i*dbeta*z) per sideband pair;
-// g  = gamma, tg = 2*gamma, ha = -alpha/2.   k = dA/dz.
+// ---- right-hand side, fused with the Runge-Kutta stage update -------------------------------------------
+// a  = [Re A1, Im A1, Re A2, ...];  returns  out = base + c * dA/dz(a)   (FUSED)   or   out = dA/dz(a)  (c = 1).
+// The stage coefficient c never appears as an instruction: the caller passes it folded into the constants
+//   g = c*gamma, tg = 2*c*gamma, ha = -c*alpha/2, (Er, Ei) = 2*c*gamma*exp(+i*dbeta*z)  per sideband pair,
+// and `base` simply seeds the FMA chain that the un-fused form would start with a multiply.
 //
-//   dA_j/dz = (ha + i*gamma*f_j) A_j + i*conj(partner) * F      (yaman_model.py:123-186)
-//   f_j = P_j + 2*sum_{k!=j} P_k = 2*S - P_j
-//   pumps:     F = E * (A_s A_i)          (exp(+i dbeta z), yaman_model.py:174,177-178)
-//   sidebands: F = conj(E) * (A_p1 A_p2)  (exp(-i dbeta z), yaman_model.py:175,180-181)
-// 64 DP instructions for NW = 4.
-template <typename T, int NW>
-__device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(NW - 2) / 2],
-                                          const T (&Ei)[(NW - 2) / 2], const T g, const T tg, const T ha,
-                                          T (&k)[2 * NW]) {
+//   dA_j/dz = (-alpha/2 + i*gamma*f_j) A_j + i*conj(partner) * F            (yaman_model.py:123-186)
+//   f_j = P_j + 2*sum_{k!=j} P_k = 2*S - P_j                                 (yaman_model.py:148-151)
+//   pumps:     F = 2*gamma*exp(+i dbeta z) * (A_s A_i)                        (yaman_model.py:174,177-178)
+//   sidebands: F = 2*gamma*exp(-i dbeta z) * (A_p1 A_p2)                      (yaman_model.py:175,180-181)
+// 64 DP instructions for NW = 4 either way (p: 8, S/g_j: 8, two products: 8, two F: 8, eight 4-deep chains: 32).
+template <typename T, int NW, bool FUSED>
+__device__ __forceinline__ void yaman_stage(const T (&a)[2 * NW], const T (&base)[2 * NW],
+                                            const T (&Er)[(NW - 2) / 2], const T (&Ei)[(NW - 2) / 2], const T g,
+                                            const T tg, const T ha, T (&out)[2 * NW]) {
     constexpr int NP = (NW - 2) / 2;
     T p[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) p[j] = fma_(a[2 * j], a[2 * j], a[2 * j + 1] * a[2 * j + 1]);
     T s = (p[0] + p[1]) + (p[2] + p[3]);
     if constexpr (NW == 6) s += (p[4] + p[5]);
-    const T gs = tg * s;  // gamma * 2S
+    const T gs = tg * s;  // c*gamma * 2S
     T gj[NW];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) gj[j] = fma_(-g, p[j], gs);  // gamma * f_j
+    for (int j = 0; j < NW; ++j) gj[j] = fma_(-g, p[j], gs);  // c*gamma * f_j
+
+    // first link of each chain: (ha * component) [+ base]
+    auto lin = [&](const int c) -> T { return FUSED ? fma_(ha, a[c], base[c]) : ha * a[c]; };
 
     const T x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3];
     const T q12r = fma_(x1, x2, -(y1 * y2)), q12i = fma_(x1, y2, y1 * x2);  // A1*A2
@@ -71,7 +76,8 @@ __device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(N
     T Fpr = T(0), Fpi = T(0);  // sum over pairs of E_p * (A_s A_i): drives both pumps
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
-        const T xs = a[4 + 4 * pr], ys = a[5 + 4 * pr], xi = a[6 + 4 * pr], yi = a[7 + 4 * pr];
+        const int cs = 4 + 4 * pr;  // component index of Re A_signal of this pair
+        const T xs = a[cs], ys = a[cs + 1], xi = a[cs + 2], yi = a[cs + 3];
         const T qr = fma_(xs, xi, -(ys * yi)), qi = fma_(xs, yi, ys * xi);  // A_s*A_i
         if (pr == 0) {
             Fpr = fma_(Er[pr], qr, -(Ei[pr] * qi));
@@ -85,17 +91,25 @@ __device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(N
         const T Fsi = fma_(Er[pr], q12i, -(Ei[pr] * q12r));
         const T gS = gj[2 + 2 * pr], gI = gj[3 + 2 * pr];
         // signal: (ha + i gS) A_s + i conj(A_i) Fs
-        k[4 + 4 * pr] = fma_(yi, Fsr, fma_(-xi, Fsi, fma_(-gS, ys, ha * xs)));
-        k[5 + 4 * pr] = fma_(xi, Fsr, fma_(yi, Fsi, fma_(gS, xs, ha * ys)));
+        out[cs] = fma_(yi, Fsr, fma_(-xi, Fsi, fma_(-gS, ys, lin(cs))));
+        out[cs + 1] = fma_(xi, Fsr, fma_(yi, Fsi, fma_(gS, xs, lin(cs + 1))));
         // idler:  (ha + i gI) A_i + i conj(A_s) Fs
-        k[6 + 4 * pr] = fma_(ys, Fsr, fma_(-xs, Fsi, fma_(-gI, yi, ha * xi)));
-        k[7 + 4 * pr] = fma_(xs, Fsr, fma_(ys, Fsi, fma_(gI, xi, ha * yi)));
+        out[cs + 2] = fma_(ys, Fsr, fma_(-xs, Fsi, fma_(-gI, yi, lin(cs + 2))));
+        out[cs + 3] = fma_(xs, Fsr, fma_(ys, Fsi, fma_(gI, xi, lin(cs + 3))));
     }
     // pump1: (ha + i g1) A1 + i conj(A2) Fp ;  pump2: (ha + i g2) A2 + i conj(A1) Fp
-    k[0] = fma_(y2, Fpr, fma_(-x2, Fpi, fma_(-gj[0], y1, ha * x1)));
-    k[1] = fma_(x2, Fpr, fma_(y2, Fpi, fma_(gj[0], x1, ha * y1)));
-    k[2] = fma_(y1, Fpr, fma_(-x1, Fpi, fma_(-gj[1], y2, ha * x2)));
-    k[3] = fma_(x1, Fpr, fma_(y1, Fpi, fma_(gj[1], x2, ha * y2)));
+    out[0] = fma_(y2, Fpr, fma_(-x2, Fpi, fma_(-gj[0], y1, lin(0))));
+    out[1] = fma_(x2, Fpr, fma_(y2, Fpi, fma_(gj[0], x1, lin(1))));
+    out[2] = fma_(y1, Fpr, fma_(-x1, Fpi, fma_(-gj[1], y2, lin(2))));
+    out[3] = fma_(x1, Fpr, fma_(y1, Fpi, fma_(gj[1], x2, lin(3))));
+}
+
+// plain dA/dz (used by the LDS-staged A/B variant, which keeps k1..k4 as such)
+template <typename T, int NW>
+__device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(NW - 2) / 2],
+                                          const T (&Ei)[(NW - 2) / 2], const T g, const T tg, const T ha,
+                                          T (&k)[2 * NW]) {
+    yaman_stage<T, NW, false>(a, a, Er, Ei, g, tg, ha, k);
 }
 
 // (Er,Ei) *= (rc,rs)
@@ -143,12 +157,18 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
 
     const double hd = A.z_max / (double)A.n_steps;  // np.linspace step
     const T h = (T)hd, hh = (T)(0.5 * hd), h6 = (T)(hd / 6.0);
+    // stage coefficients folded into the physics constants: d = h/2 (stages 1, 2, 4) and h (stage 3)
+    const T g_d = hh * g, tg_d = hh * tg, ha_d = hh * ha;
+    const T g_h = h * g, tg_h = h * tg, ha_h = h * ha;
+    const T third = T(1.0 / 3.0);
+    constexpr bool FUSE = (sizeof(T) == 8) && !LDS;   // fused-stage step: float64 register variant only
+    const T e_amp = FUSE ? tg_d : tg;  // modulus of the carried phase factor: 2*d*gamma (fused) or 2*gamma
 
     T rc[NP], rs[NP], Er[NP], Ei[NP];  // half-step rotator and the running 2*gamma*exp(i dbeta z)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         Phase<T>::eval(dbd[p] * (0.5 * hd), rc[p], rs[p]);
-        Er[p] = tg;
+        Er[p] = e_amp;
         Ei[p] = T(0);
     }
 
@@ -208,9 +228,44 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
         }
     };
 
-    // ---- one classic RK4 step (integrators.py:54-59), low storage: y, y_stage, accumulator.
-    // On entry (Er,Ei) = 2*gamma*exp(i*dbeta*z_step); on exit it has been rotated to z_step + h.
+    // ---- one classic RK4 step (integrators.py:54-59) in 298 DP instructions (4 waves).
+    // Each stage's axpy is folded into the RHS chains (yaman_stage, FUSED): with d = h/2
+    //     Y2 = y + d*f(z, y)          Y3 = y + d*f(z+d, Y2)          Y4 = y + 2d*f(z+d, Y3)
+    //     t  = Y2 + 2*Y3 + Y4 - 4*y                 ( = d*k1 + 2d*k2 + 2d*k3 )
+    //     D  = t + d*f(z+h, Y4)                     ( = d*(k1 + 2*k2 + 2*k3 + k4) )
+    //     y <- y + D/3                              ( = y + h/6*(k1 + 2*k2 + 2*k3 + k4) )
+    // which is the reference's k1..k4 combination regrouped (no change of variables, same truncation error; the
+    // regrouping costs ~1 ulp(y) of rounding noise per step, ~1e-13 after 1e5 steps).  (Ed_r, Ed_i) carries
+    // 2*d*gamma*exp(i*dbeta*z): on entry at z_step, on exit rotated to z_step + h.
     auto rk4_step_reg = [&](const int step_index) {
+        T Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
+        yaman_stage<T, NW, true>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);  // Y2 = y + d k1
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h/2
+        yaman_stage<T, NW, true>(Y2, y, Er, Ei, g_d, tg_d, ha_d, Y3);  // Y3 = y + d k2
+        T E2r[NP], E2i[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            E2r[p] = Er[p] + Er[p];
+            E2i[p] = Ei[p] + Ei[p];
+        }
+        yaman_stage<T, NW, true>(Y3, y, E2r, E2i, g_h, tg_h, ha_h, Y4);  // Y4 = y + h k3
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t[c] = fma_(T(2), Y3[c], fma_(T(-4), y[c], Y2[c])) + Y4[c];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h
+        yaman_stage<T, NW, true>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);  // D = t + d k4
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
+        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step (a select, not a branch)
+            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
+        }
+    };
+
+    // ---- float32: the classic low-storage form (y, y_stage, accumulator; 320 instructions).  The regrouping above
+    // quantises every stage increment to ulp(y); harmless at 1e-16 but measured 17x worse at float32 (6.7e-3 vs
+    // 3.8e-4 relative after 1e4 steps), so single precision keeps k1..k4 at full precision.
+    auto rk4_step_classic = [&](const int step_index) {
         T k[NC], ys[NC], acc[NC];
         yaman_rhs<T, NW>(y, Er, Ei, g, tg, ha, k);  // k1 at z
 #pragma unroll
@@ -237,9 +292,13 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
         yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k4
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(h6, acc[c] + k[c], y[c]);
-        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step (a select, not a branch)
+        if constexpr (CHECK == CHECK_EXACT) {
             if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
         }
+    };
+    auto rk4_step = [&](const int step_index) {
+        if constexpr (FUSE) rk4_step_reg(step_index);
+        else rk4_step_classic(step_index);
     };
 
     // ---- z-loop, event driven: the steps between two events (a saved row, a phase re-seed, the end) run in a
@@ -257,8 +316,8 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
             for (int p = 0; p < NP; ++p) {
                 T c, s;
                 Phase<T>::eval(dbd[p] * z, c, s);
-                Er[p] = tg * c;
-                Ei[p] = tg * s;
+                Er[p] = e_amp * c;
+                Ei[p] = e_amp * s;
             }
             since_seed = 0;
         }
@@ -271,10 +330,10 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
             for (; j < m; ++j) rk4_step_lds(i + j);
         } else {
             for (; j + 2 <= m; j += 2) {
-                rk4_step_reg(i + j);
-                rk4_step_reg(i + j + 1);
+                rk4_step(i + j);
+                rk4_step(i + j + 1);
             }
-            if (j < m) rk4_step_reg(i + j);
+            if (j < m) rk4_step(i + j);
         }
         i = end;
         since_seed += m;

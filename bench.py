@@ -110,8 +110,12 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under torch.distributed.run (RANK set) the gather path is used even for one rank, so the RCCL plumbing can be
+    # rehearsed on a one-GPU box; plain `python bench.py` stays collective-free.
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("PSA_BENCH_DIST_ON_ONE", "0") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     # -- synthetic inputs of the workload, resident in HBM (rank's contiguous block of the global sweep)
@@ -128,12 +132,12 @@ def main() -> None:
         sweep.launch()
         if ev1 is not None:
             ev1.record()
-        return sweep.gather() if world > 1 else None
+        return sweep.gather() if use_dist else None
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -142,11 +146,11 @@ def main() -> None:
     for e0, e1 in events:
         gathered = one_step(e0, e1)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
@@ -154,7 +158,7 @@ def main() -> None:
 
     # -- post-run guard (not timed): the numbers just produced are the right numbers
     res = sweep.result()
-    if world > 1:
+    if use_dist:
         assert gathered is not None and torch.equal(gathered[rank], sweep.record)
     verify = None
     if rank == 0:
@@ -207,7 +211,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

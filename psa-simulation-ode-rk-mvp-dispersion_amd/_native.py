@@ -69,10 +69,31 @@ class PsaNativeError(RuntimeError):
 _LIB: Optional[C.CDLL] = None
 
 
+def _pin_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` with the same SONAME
+    as /opt/rocm's; whichever is mapped first serves every later dlopen of that SONAME.  If torch is installed but
+    not imported yet, map ITS copy now, so that a later ``import torch`` (bench.py, the multi-GPU driver) and this
+    library share device pointers and streams whatever the import order.  PSA_HIP_RUNTIME=system skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PSA_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall through to the system runtime; a mismatch would surface as a loud HIP error, not a wrong result
+
+
 def lib() -> C.CDLL:
     """Load the shared library once; raise loudly if it is not there."""
     global _LIB
     if _LIB is None:
+        _pin_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise NativeUnavailableError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "

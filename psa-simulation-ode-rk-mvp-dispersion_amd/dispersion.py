@@ -29,16 +29,16 @@ def _real(x, name: str) -> float:
     try:
         v = float(x)
     except Exception as e:
-        raise TypeError(f"{name} must be a real scalar, got {type(x)!r}") from e
+        raise TypeError(f"{name}: not a real scalar ({type(x).__name__})") from e
     if not np.isfinite(v):
-        raise ValueError(f"{name} must be finite, got {v!r}")
+        raise ValueError(f"{name}: not finite ({v!r})")
     return v
 
 
 def _positive(x, name: str) -> float:
     v = _real(x, name)
     if v <= 0.0:
-        raise ValueError(f"{name} must be > 0, got {v!r}")
+        raise ValueError(f"{name}: needs a positive value ({v!r})")
     return v
 
 
@@ -91,13 +91,13 @@ class DispersionParams:
             object.__setattr__(self, f"beta{n}", _real(getattr(self, f"beta{n}"), f"beta{n}"))
         if self.extra is not None:
             if not isinstance(self.extra, dict):
-                raise TypeError("extra must be a dict {order:int -> beta_order:float} or None")
+                raise TypeError("extra: a dict order -> coefficient, or None")
             cleaned = {}
             for k, v in self.extra.items():
                 if not isinstance(k, int):
-                    raise TypeError(f"extra key must be int order, got {type(k)!r}")
+                    raise TypeError(f"extra: order {k!r} is not an int")
                 if k < 0:
-                    raise ValueError(f"extra order must be >= 0, got {k}")
+                    raise ValueError(f"extra: negative order {k}")
                 cleaned[k] = _real(v, f"extra[{k}]")
             object.__setattr__(self, "extra", cleaned)
 
@@ -135,9 +135,9 @@ def beta_taylor(omega: ArrayLike, disp: DispersionParams, *, max_order: int = 4)
         raise ValueError("max_order must be >= 0")
     w = np.asarray(omega, dtype=float)
     if not np.all(np.isfinite(w)):
-        raise ValueError("omega must be finite")
+        raise ValueError("omega: non-finite")
     if np.any(w <= 0.0):
-        raise ValueError("omega must be positive (rad/s)")
+        raise ValueError("omega: must be > 0 rad/s")
     acc = _taylor_sum(w - disp.omega_ref, disp, max_order)
     return float(acc.item()) if np.isscalar(omega) else acc
 
@@ -162,15 +162,14 @@ def delta_beta_from_omegas(omegas: Sequence[float], disp: DispersionParams, *, m
                            atol: float = 0.0, rtol: float = 1e-12) -> float:
     om = np.asarray(list(omegas), dtype=float)
     if om.shape != (4,):
-        raise ValueError(f"omegas must have shape (4,), got {om.shape}")
+        raise ValueError(f"omegas: four entries expected, shape is {om.shape}")
     if not np.all(np.isfinite(om)):
-        raise ValueError("omegas must be finite")
+        raise ValueError("omegas: non-finite entry")
     if np.any(om <= 0.0):
-        raise ValueError("omegas must be positive (rad/s)")
+        raise ValueError("omegas: entries must be > 0 rad/s")
     lhs, rhs = om[0] + om[1], om[2] + om[3]
     if not np.isclose(lhs, rhs, atol=atol, rtol=rtol):
-        raise ValueError("Energy conservation violated: omega1+omega2 != omega3+omega4. "
-                         f"(lhs={lhs:.16e}, rhs={rhs:.16e}, diff={(lhs - rhs):.16e})")
+        raise ValueError(f"w1 + w2 = {lhs:.16e} but w3 + w4 = {rhs:.16e}: photon energy is not conserved")
     if not isinstance(max_order, int):
         raise TypeError("max_order must be int")
     if max_order < 0:
@@ -183,14 +182,14 @@ def delta_beta_from_omegas(omegas: Sequence[float], disp: DispersionParams, *, m
 def _check_even_orders(even_orders: Iterable[int]) -> list:
     evens = list(even_orders)
     if not evens:
-        raise ValueError("even_orders must contain at least one order (e.g., 2,4)")
+        raise ValueError("even_orders: empty")
     for n in evens:
         if not isinstance(n, int):
-            raise TypeError("even_orders must contain ints")
+            raise TypeError("even_orders: ints only")
         if n < 2:
-            raise ValueError(f"even order must be >=2, got {n}")
+            raise ValueError(f"even_orders: {n} < 2")
         if n % 2:
-            raise ValueError(f"Order must be even, got {n}")
+            raise ValueError(f"even_orders: {n} is odd")
     return evens
 
 

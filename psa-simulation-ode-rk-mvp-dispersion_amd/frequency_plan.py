@@ -24,16 +24,16 @@ def _finite_scalar(x, name: str) -> float:
     try:
         v = float(x)
     except Exception as e:
-        raise TypeError(f"{name} must be a real scalar, got {type(x)!r}") from e
+        raise TypeError(f"{name}: not a real scalar ({type(x).__name__})") from e
     if not np.isfinite(v):
-        raise ValueError(f"{name} must be finite, got {v!r}")
+        raise ValueError(f"{name}: not finite ({v!r})")
     return v
 
 
 def _positive_scalar(x, name: str, unit: str) -> float:
     v = _finite_scalar(x, name)
     if v <= 0.0:
-        raise ValueError(f"{name} must be > 0 ({unit}), got {v!r}")
+        raise ValueError(f"{name}: needs a positive value in {unit} ({v!r})")
     return v
 
 
@@ -62,11 +62,11 @@ def omega_from_lambda_array(lambda_m) -> np.ndarray:
 def _omega4(om) -> np.ndarray:
     arr = np.asarray(list(om), dtype=float)
     if arr.shape != (4,):
-        raise ValueError(f"omega must have shape (4,), got {arr.shape}")
+        raise ValueError(f"omega: four entries expected, shape is {arr.shape}")
     if not np.all(np.isfinite(arr)):
-        raise ValueError("omega must contain only finite values")
+        raise ValueError("omega: non-finite entry")
     if np.any(arr <= 0.0):
-        raise ValueError("omega must contain only positive angular frequencies (rad/s)")
+        raise ValueError("omega: entries must be > 0 rad/s")
     return arr
 
 
@@ -80,8 +80,8 @@ def enforce_energy_conservation(omega, *, atol: float = 0.0, rtol: float = 1e-12
     om = _omega4(omega)
     lhs, rhs = om[0] + om[1], om[2] + om[3]
     if not bool(_conserves(lhs, rhs, atol, rtol)):
-        raise ValueError("Energy conservation violated: omega1+omega2 != omega3+omega4. "
-                         f"(lhs={lhs:.16e}, rhs={rhs:.16e}, diff={lhs - rhs:.16e})")
+        raise ValueError(f"w1 + w2 = {lhs:.16e} but w3 + w4 = {rhs:.16e} (difference {lhs - rhs:.3e}): "
+                         "photon energy is not conserved by this plan")
 
 
 # ---- symmetric representation (frequency_plan.py:134-199) ------------------------------------------
@@ -97,8 +97,7 @@ class SymmetricPlan:
         od = _finite_scalar(self.omega_d, "omega_d")
         Om = _finite_scalar(self.Omega, "Omega")
         if abs(od) >= oc:
-            raise ValueError("Invalid symmetric plan: |omega_d| must be < omega_c to keep omega1, omega2 positive. "
-                             f"Got omega_c={oc!r}, omega_d={od!r}")
+            raise ValueError(f"|omega_d| = {abs(od)!r} >= omega_c = {oc!r}: a pump frequency would be <= 0")
         for k, v in (("omega_c", oc), ("omega_d", od), ("Omega", Om)):
             object.__setattr__(self, k, v)
 
@@ -110,9 +109,7 @@ class SymmetricPlan:
     def omegas(self) -> np.ndarray:
         om = np.array([self.omega1, self.omega2, self.omega3, self.omega4], dtype=float)
         if np.any(om <= 0.0):
-            raise ValueError("This symmetric plan produces non-positive omega for signal/idler. "
-                             f"Computed omega=[{om[0]:.6e}, {om[1]:.6e}, {om[2]:.6e}, {om[3]:.6e}] rad/s. "
-                             "Adjust Omega and/or omega_c.")
+            raise ValueError(f"signal/idler frequency <= 0 for this (omega_c, Omega): {om.tolist()}")
         enforce_energy_conservation(om)
         return om
 
@@ -179,8 +176,7 @@ def infer_symmetry_from_omegas(omega1: float, omega2: float, omega3: float, omeg
     sp = SymmetricPlan(omega_c=oc, omega_d=0.5 * (w1 - w2), Omega=w3 - oc)
     back = sp.omegas()
     if not bool(_conserves(back[3], w4, atol, rtol)):
-        raise ValueError("Inferred symmetric parameters are inconsistent with omega4. "
-                         f"omega4(target)={w4:.16e}, omega4(from symmetry)={back[3]:.16e}")
+        raise ValueError(f"symmetric form gives w4 = {back[3]:.16e}, expected {w4:.16e}")
     return sp
 
 

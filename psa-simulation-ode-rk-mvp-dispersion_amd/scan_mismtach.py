@@ -4,6 +4,8 @@
 * ``plot_max_gain_and_dbeta_vs_lambda_signal(...) -> (x, gain_max, dbeta)``  reference scan_mismtach.py:588-783
 * ``scan_dbeta_seeded_signal(...)``: a working direct-dbeta scan with gain_mode "end" | "max" and the
   argmax-over-sweep summary -- what the reference's dead ``scan_mismatch_seeded_signal`` (:43-259) set out to do.
+* ``scan_gain_grid(...)``: the same sweep over a 2-D (pump-2 wavelength x signal wavelength) grid in one launch
+  (BASELINE config 3's shape: 1024 x 1024 points); the reference has no grid builder.
 
 Where the reference loops over lambda3 in Python and calls ``run_single_simulation`` per point, these drivers
 build every plan and every dbeta at once on the host (``plan_from_wavelengths_batch``,
@@ -269,3 +271,46 @@ def scan_dbeta_seeded_signal(*, cfg: SimulationConfig, delta_beta: Sequence[floa
     secs = max(res.elapsed_ms, 1e-9) * 1e-3
     return dict(delta_beta=db, gain=gain, best_index=bi, best_delta_beta=(float(db[bi]) if bi >= 0 else float("nan")),
                 best_gain=bg, n_finite=nf, result=res, points_per_s=db.size / secs)
+
+
+def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Sequence[float],
+                   lambda_signal_m: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
+                   phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
+                   phase_matching_cfg: Optional[PhaseMatchingConfig] = None, length_unit: str = "m",
+                   gain_unit: str = "dB", gain_mode: GainMode = "max", device: int = 0) -> dict:
+    """Signal gain over the grid lambda_p2[Ny] x lambda_signal[Nx]: Ny*Nx independent runs, one kernel launch.
+
+    Row iy is exactly what ``plot_max_gain_and_dbeta_vs_lambda_signal(lambda_p2_m=lambda_p2[iy], ...)`` returns
+    (same plans, same dbeta, same NaN rules).  Returns dict(gain (Ny, Nx), dbeta (Ny, Nx) in 1/length_unit,
+    best_index (iy, ix) | None, best_gain, n_finite, result=SweepResult | None).
+    """
+    if gain_mode not in ("end", "max"):
+        raise ValueError(f"Unknown gain_mode={gain_mode!r}. Use 'end' or 'max'.")
+    unit = _norm_choice(gain_unit, "gain_unit", ("db", "linear"))
+    lam3, p0, ph0 = _check_sweep_inputs(lambda_signal_m, p_in, phase_in)
+    lam2 = np.asarray(list(lambda_p2_m), dtype=float)
+    if lam2.ndim != 1 or lam2.size == 0 or not np.all(np.isfinite(lam2)) or np.any(lam2 <= 0.0):
+        raise ValueError("lambda_p2_m must be a non-empty 1D sequence of finite positive wavelengths (m)")
+    if dispersion is None:
+        raise ValueError("dispersion must be provided")
+    pm_cfg = phase_matching_cfg if phase_matching_cfg is not None else PhaseMatchingConfig()
+    L2, L3 = np.meshgrid(lam2, lam3, indexing="ij")
+    l2, l3 = L2.ravel(), L3.ravel()
+    try:
+        omega, ok = plan_from_wavelengths_batch(float(lambda_p1_m), l2, l3)
+        dbeta, ok_db = compute_phase_mismatch_batch(omega, dispersion, pm_cfg)
+        dbeta = np.where(ok & ok_db, dbeta, np.nan)
+    except Exception:
+        dbeta = np.full(l3.shape, np.nan)
+    gain, _, res = _sweep_gain(cfg=cfg, lam1=float(lambda_p1_m), lam2=l2, lam3=l3, gamma=gamma, alpha=alpha, p0=p0,
+                               ph0=ph0, dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
+                               gain_mode=gain_mode, device=device)
+    gain = np.where(np.isnan(dbeta), np.nan, gain)
+    finite = np.isfinite(gain)
+    best = None
+    if finite.any():
+        flat = int(np.nanargmax(gain))
+        best = (flat // lam3.size, flat % lam3.size)
+    return dict(gain=gain.reshape(lam2.size, lam3.size), dbeta=dbeta.reshape(lam2.size, lam3.size), best_index=best,
+                best_gain=(float(gain.reshape(-1)[best[0] * lam3.size + best[1]]) if best else float("nan")),
+                n_finite=int(finite.sum()), result=res)

@@ -181,3 +181,54 @@ def test_direct_dbeta_scan_end_and_max_modes(golden):
     rk = scan_mismtach.scan_dbeta_seeded_signal(cfg=cfg_km, delta_beta=g["dbeta257"] * 1e3, gamma=11.5, alpha=0.115,
                                                 p_in=g["p_in"], length_unit="km", gain_mode="max", gain_unit="linear")
     np.testing.assert_allclose(rk["gain"], g["n1e4_a1_p_max"] / g["p_in"][2], rtol=1e-8)
+
+
+def test_sharded_sweep_through_rccl_with_one_rank(oracle):
+    """The nccl (= RCCL) leg of distributed.sweep_sharded / DeviceSweep.gather on the one GPU this box has:
+    world_size 1, rendezvous on 127.0.0.1.  (world_size 2 is covered on CPU with gloo.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from psa_amd.distributed import DeviceSweep, sweep_sharded, unpack_records
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        db = np.linspace(-0.05, 0.05, 333)
+        a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
+        ref = oracle.sweep(db, z_max=50.0, n=500, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+        res = sweep_sharded(db, n_steps=500, z_max=50.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+        assert rel_err(res.a_end, ref["a_end"]) < RTOL_F64 and np.array_equal(res.first_bad_step, ref["first_bad_step"])
+        ds = DeviceSweep(db, n_steps=500, z_max=50.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+        ds.launch()
+        g = ds.gather()
+        torch.cuda.synchronize()
+        a, pe, pm, fb = unpack_records(g.cpu().numpy(), db.size, 1, 4)
+        assert np.array_equal(a, res.a_end) and np.array_equal(pm, res.p_max) and (fb == -1).all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grid_scan_rows_equal_the_1d_driver(golden):
+    """scan_gain_grid (config 3's 2-D shape, here 5 x 16): every row must equal the reference-shaped 1-D driver."""
+    g = golden("G11")
+    dv = g["disp_m"]
+    d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3])
+    cfg = config.custom_simulation_config(z_max=300.0, dz=0.25, save_every=7)
+    lam2 = np.array([1556e-9, 1553e-9, 1558e-9, 0.5e-6, 1560e-9])     # incl. a far-detuned (but valid) pump 2
+    kw = dict(cfg=cfg, lambda_p1_m=1550e-9, gamma=0.0115, alpha=1.0e-4, p_in=g["p_in"], phase_in=g["phase_in"],
+              dispersion=d, length_unit="m", gain_unit="linear")
+    grid = scan_mismtach.scan_gain_grid(lambda_p2_m=lam2, lambda_signal_m=g["lambda3"], **kw)
+    assert grid["gain"].shape == (5, 16) and grid["dbeta"].shape == (5, 16)
+    np.testing.assert_allclose(grid["gain"][0], g["m_gain"], rtol=RTOL_F64)       # row 0 is golden G11 itself
+    assert np.array_equal(grid["dbeta"][0], g["m_dbeta"])
+    for iy, l2 in enumerate(lam2):
+        x, gain, db = scan_mismtach.plot_max_gain_and_dbeta_vs_lambda_signal(
+            lambda_p2_m=float(l2), lambda_signal_m=g["lambda3"], return_wavelength_unit="m", show=False, **kw)
+        assert np.array_equal(grid["gain"][iy], gain, equal_nan=True) and np.array_equal(grid["dbeta"][iy], db, equal_nan=True)
+    iy, ix = grid["best_index"]
+    assert grid["best_gain"] == np.nanmax(grid["gain"]) == grid["gain"][iy, ix]
+    assert grid["n_finite"] == int(np.isfinite(grid["gain"]).sum())

@@ -159,7 +159,7 @@ def main() -> None:
     # -- post-run guard (not timed): the numbers just produced are the right numbers
     res = sweep.result()
     if use_dist:
-        assert gathered is not None and torch.equal(gathered[rank], sweep.record)
+        assert gathered is not None and torch.equal(gathered[rank].view(torch.int64), sweep.record.view(torch.int64))
     verify = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -111,9 +111,10 @@ def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, ga
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     t_local = torch.from_numpy(rec).to(dev)
-    t_all = torch.empty(world * t_local.numel(), dtype=torch.float64, device=dev)   # flat: rank-major concatenation
-    dist.all_gather_into_tensor(t_all, t_local.reshape(-1), group=group)   # the single collective of the path
-    gathered = t_all.cpu().numpy().reshape((world,) + tuple(t_local.shape))
+    # shipped as int64 words: a pure bit copy (first_bad_step = -1 is a NaN pattern when read as float64)
+    t_all = torch.empty(world * t_local.numel(), dtype=torch.int64, device=dev)   # flat: rank-major concatenation
+    dist.all_gather_into_tensor(t_all, t_local.reshape(-1).view(torch.int64), group=group)   # the single collective
+    gathered = t_all.view(torch.float64).cpu().numpy().reshape((world,) + tuple(t_local.shape))
     a_end, p_end, p_max, first_bad = unpack_records(gathered, N, world, nw)
     return SweepResult(a_end, p_end, p_max, first_bad, int(n_steps), int(save_every),
                        float(local.get("elapsed_ms", 0.0)))
@@ -162,9 +163,9 @@ class DeviceSweep:
     def gather(self, group=None) -> torch.Tensor:
         """One all_gather of the record over the process group -> (world, rows, n_local) on this GPU."""
         world = dist.get_world_size(group)
-        out = torch.empty(world * self.record.numel(), dtype=torch.float64, device=self.device)
-        dist.all_gather_into_tensor(out, self.record.reshape(-1), group=group)
-        return out.reshape((world,) + tuple(self.record.shape))
+        out = torch.empty(world * self.record.numel(), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, self.record.reshape(-1).view(torch.int64), group=group)   # bit copy
+        return out.view(torch.float64).reshape((world,) + tuple(self.record.shape))
 
     def result(self) -> SweepResult:
         rec = self.record.cpu().numpy()

@@ -99,6 +99,12 @@ def main() -> None:
     ap.add_argument("--exact-step", action="store_true", help="per-step finite test instead of per save block")
     args = ap.parse_args()
 
+    # Exactly ONE line may reach stdout (the JSON, from rank 0).  RCCL prints a version banner with printf at
+    # communicator creation, so fd 1 is pointed at stderr for the run and restored only for the final print.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,7 +216,12 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if use_dist:
+            torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

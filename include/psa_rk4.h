@@ -64,6 +64,9 @@ extern "C" {
 #define PSA_OPT_LDS_STAGING  (1u << 10)  /* keep y / y_stage / k-accumulator in LDS instead of VGPRs (the layout
                                             the north-star sketches; slower -- kept for the A/B in DESIGN.md)    */
 #define PSA_OPT_BLOCK64      (1u << 11)  /* 64-thread workgroups (one wave) instead of 256                       */
+#define PSA_OPT_F32_SCALAR   (1u << 12)  /* float32 only: force one sweep point per lane                          */
+#define PSA_OPT_F32_PACKED   (1u << 13)  /* float32 only: force two points per lane (v_pk_fma_f32 packed math);
+                                            this is also the default whenever n_points >= 2                      */
 
 /* ---- environment ----------------------------------------------------------- */
 int         psa_device_count(void);          /* number of visible HIP devices (0 if none / no driver) */

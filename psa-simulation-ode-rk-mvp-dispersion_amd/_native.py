@@ -30,6 +30,8 @@ OPT_CHECK_NAN = 1 << 8
 OPT_EXACT_STEP = 1 << 9
 OPT_LDS_STAGING = 1 << 10
 OPT_BLOCK64 = 1 << 11
+OPT_F32_SCALAR = 1 << 12
+OPT_F32_PACKED = 1 << 13
 
 # every symbol the header declares, with (restype, argtypes)
 _P = C.c_void_p

@@ -86,7 +86,8 @@ psa::SweepArgs<T> make_args(int n_waves, int64_t n_points, int64_t n_steps, doub
 
 template <typename T> struct Launch;
 template <> struct Launch<double> {
-    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, const psa::SweepArgs<double> &a) {
+    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t /*flags*/,
+                            const psa::SweepArgs<double> &a) {
         return psa::launch_sweep_f64(s, nw, chk, lds, blk, a);
     }
     static hipError_t a2s(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_aos_to_soa_f64(s, a, b, n, nc); }
@@ -94,8 +95,10 @@ template <> struct Launch<double> {
     static hipError_t t2a(hipStream_t s, const double *a, double *b, long long n, long long r, int nc) { return psa::launch_traj_to_aos_f64(s, a, b, n, r, nc); }
 };
 template <> struct Launch<float> {
-    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, const psa::SweepArgs<float> &a) {
-        return psa::launch_sweep_f32(s, nw, chk, lds, blk, a);
+    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
+                            const psa::SweepArgs<float> &a) {
+        const int pack = (flags & PSA_OPT_F32_PACKED) ? 1 : ((flags & PSA_OPT_F32_SCALAR) ? 0 : -1);
+        return psa::launch_sweep_f32(s, nw, chk, lds, blk, pack, a);
     }
     static hipError_t a2s(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_aos_to_soa_f32(s, a, b, n, nc); }
     static hipError_t s2a(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_soa_to_aos_f32(s, a, b, n, nc); }
@@ -113,7 +116,7 @@ int sweep_dev(void *stream, int n_waves, int64_t n_points, int64_t n_steps, doub
     auto a = make_args<T>(n_waves, n_points, n_steps, z_max, save_every, d_dbeta, d_dbeta2, d_gamma, d_alpha,
                           d_a0_soa, flags, d_a_end_soa, d_p_end, d_p_max, d_first_bad, d_traj_soa);
     hipError_t e = Launch<T>::sweep((hipStream_t)stream, n_waves, check_mode(flags), (flags & PSA_OPT_LDS_STAGING) != 0,
-                                    (flags & PSA_OPT_BLOCK64) ? 64 : 256, a);
+                                    (flags & PSA_OPT_BLOCK64) ? 64 : 256, flags, a);
     if (e != hipSuccess) return hip_fail(e, "rk4_sweep launch");
     return PSA_OK;
 }

@@ -31,7 +31,8 @@ enum CheckMode : int { CHECK_NONE = 0, CHECK_BLOCK = 1, CHECK_EXACT = 2 };
 
 // launchers (defined in psa_rk4_f64.hip / psa_rk4_f32.hip)
 hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<double> &a);
-hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<float> &a);
+hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack,
+                            const SweepArgs<float> &a);  // pack: 1 two points/lane, 0 one, -1 auto
 
 // aux kernels (psa_aux.hip)
 hipError_t launch_aos_to_soa_f64(hipStream_t s, const double *aos, double *soa, long long n, int nc);

@@ -25,6 +25,9 @@ namespace psa {
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// two float32 sweep points per lane: <2 x float> arithmetic selects v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // cos/sin of a float64 phase, delivered in the working precision.
 template <typename T> struct Phase;
@@ -73,7 +76,7 @@ __device__ __forceinline__ void yaman_stage(const T (&a)[2 * NW], const T (&base
     const T x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3];
     const T q12r = fma_(x1, x2, -(y1 * y2)), q12i = fma_(x1, y2, y1 * x2);  // A1*A2
 
-    T Fpr = T(0), Fpi = T(0);  // sum over pairs of E_p * (A_s A_i): drives both pumps
+    T Fpr = T{}, Fpi = T{};  // sum over pairs of E_p * (A_s A_i): drives both pumps
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
         const int cs = 4 + 4 * pr;  // component index of Re A_signal of this pair
@@ -265,6 +268,9 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     // ---- float32: the classic low-storage form (y, y_stage, accumulator; 320 instructions).  The regrouping above
     // quantises every stage increment to ulp(y); harmless at 1e-16 but measured 17x worse at float32 (6.7e-3 vs
     // 3.8e-4 relative after 1e4 steps), so single precision keeps k1..k4 at full precision.
+    T y_lo[NC];  // Kahan residue of the state (float32 path only)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) y_lo[c] = T{};
     auto rk4_step_classic = [&](const int step_index) {
         T k[NC], ys[NC], acc[NC];
         yaman_rhs<T, NW>(y, Er, Ei, g, tg, ha, k);  // k1 at z
@@ -290,8 +296,15 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h
         yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k4
+        // compensated (Kahan) state update: keeps the part of the increment that y + inc rounds away (see the
+        // packed kernel); without it float32 drifts ~n * ulp and misses its 1e-3 tolerance at 1e6 steps.
 #pragma unroll
-        for (int c = 0; c < NC; ++c) y[c] = fma_(h6, acc[c] + k[c], y[c]);
+        for (int c = 0; c < NC; ++c) {
+            const T inc = fma_(h6, acc[c] + k[c], y_lo[c]);
+            const T sum = y[c] + inc;
+            y_lo[c] = inc - (sum - y[c]);
+            y[c] = sum;
+        }
         if constexpr (CHECK == CHECK_EXACT) {
             if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
         }
@@ -321,8 +334,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
             }
             since_seed = 0;
         }
-        int end = i + CHUNK;
-        end = end < n_run ? end : n_run;
+        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;   // no overflow near 2^31 steps
         end = end < next_save ? end : next_save;
         const int m = end - i;
         int j = 0;

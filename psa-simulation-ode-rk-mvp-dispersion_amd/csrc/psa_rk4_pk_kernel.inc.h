@@ -1,0 +1,194 @@
+// psa_rk4_pk_kernel.inc.h -- float32 sweep with TWO sweep points per lane (packed math), gfx950.
+//
+// Why: a float32 VALU instruction occupies a SIMD for 2 cycles per wave64, but a lone wave can only issue one every
+// 4 -- so the scalar float32 kernel runs no faster than the float64 one whenever a sweep gives each SIMD a single
+// wave (131 072 points per GPU in BASELINE config 4).  Packing points (2i, 2i+1) into the two halves of a 64-bit
+// register pair turns every instruction of the step into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
+// instruction count advances twice the points.  Same algorithm and arithmetic as the scalar float32 kernel
+// (classic low-storage RK4 on the un-fused RHS with a compensated state update, phase factor re-seeded from a
+// float64-reduced sincos every <= 16 steps), so the two agree to rounding.
+#pragma once
+#include "psa_rk4_kernel.inc.h"
+
+namespace psa {
+
+__device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
+
+template <int NW, int CHECK, bool TRAJ, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<float> A) {
+    using V = f32x2;
+    constexpr int NC = 2 * NW;
+    constexpr int NP = (NW - 2) / 2;
+    constexpr int RESYNC = Phase<float>::RESYNC;
+    const long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long N = A.n_points;
+    const long long pt[2] = {2 * idx, (2 * idx + 1 < N) ? 2 * idx + 1 : 2 * idx};  // odd tail: slot 1 mirrors slot 0
+    if (pt[0] >= N) return;
+    const bool live1 = 2 * idx + 1 < N;  // slot 1 holds a real point (else computed but never stored)
+
+    V y[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float *row = A.a0 + (long long)c * A.a0_ld;
+        y[c] = (V){row[pt[0] * A.a0_stride], row[pt[1] * A.a0_stride]};
+    }
+    const V g = (V){A.gamma[pt[0] * A.gamma_stride], A.gamma[pt[1] * A.gamma_stride]};
+    const V tg = g + g;
+    const V ha = splat2(-0.5f) * (V){A.alpha[pt[0] * A.alpha_stride], A.alpha[pt[1] * A.alpha_stride]};
+    double dbd[NP][2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        dbd[0][w] = (double)A.dbeta[pt[w]];
+        if constexpr (NP == 2) dbd[1][w] = (double)A.dbeta2[pt[w]];
+    }
+    const double hd = A.z_max / (double)A.n_steps;
+    const V h = splat2((float)hd), hh = splat2((float)(0.5 * hd)), h6 = splat2((float)(hd / 6.0));
+    const V two = splat2(2.0f);
+
+    V rc[NP], rs[NP], Er[NP], Ei[NP];
+    auto seed = [&](const double z, V (&outc)[NP], V (&outs)[NP], const V amp) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float c0, s0, c1, s1;
+            Phase<float>::eval(dbd[p][0] * z, c0, s0);
+            Phase<float>::eval(dbd[p][1] * z, c1, s1);
+            outc[p] = amp * (V){c0, c1};
+            outs[p] = amp * (V){s0, s1};
+        }
+    };
+    seed(0.5 * hd, rc, rs, splat2(1.0f));   // half-step rotator exp(i*dbeta*h/2)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { Er[p] = tg; Ei[p] = V{}; }
+
+    V y_lo[NC];  // Kahan residue of the state
+#pragma unroll
+    for (int c = 0; c < NC; ++c) y_lo[c] = V{};
+    V pe = fma_(y[4], y[4], y[5] * y[5]);
+    V pm = pe;
+    long long bad[2] = {-1, -1};
+    auto track = [&](const int step) {  // sum_c 0*y_c is NaN exactly for a non-finite component, per packed half
+        V t = V{};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t = fma_(y[c], V{}, t);
+        if (bad[0] < 0 && t.x != t.x) bad[0] = step;
+        if (bad[1] < 0 && t.y != t.y) bad[1] = step;
+    };
+    auto store_rows = [&](float *base) {  // base[c * N + point]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            base[(long long)c * N + pt[0]] = y[c].x;
+            if (live1) base[(long long)c * N + pt[1]] = y[c].y;
+        }
+    };
+
+    const int se = A.save_every;
+    const int n_rows = A.n_steps / se;
+    const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;
+    if constexpr (TRAJ) store_rows(A.traj);
+    if (n_rows == 0) store_rows(A.a_end);
+
+    auto rk4_step = [&](const int step_index) {  // integrators.py:54-59, low storage: y, y_stage, accumulator
+        V k[NC], ys[NC], acc[NC];
+        yaman_rhs<V, NW>(y, Er, Ei, g, tg, ha, k);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { acc[c] = k[c]; ys[c] = fma_(hh, k[c], y[c]); }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);
+        yaman_rhs<V, NW>(ys, Er, Ei, g, tg, ha, k);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { acc[c] = fma_(two, k[c], acc[c]); ys[c] = fma_(hh, k[c], y[c]); }
+        yaman_rhs<V, NW>(ys, Er, Ei, g, tg, ha, k);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { acc[c] = fma_(two, k[c], acc[c]); ys[c] = fma_(h, k[c], y[c]); }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);
+        yaman_rhs<V, NW>(ys, Er, Ei, g, tg, ha, k);
+        // compensated state update: the increment (~1e-5 |y| at 1e6 steps) is added with its rounding residue kept
+        // in y_lo, otherwise float32 loses it at ulp(y) per step and the error grows ~n (5e-3 at 1e6 steps).
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const V inc = fma_(h6, acc[c] + k[c], y_lo[c]);  // increment + carried residue
+            const V sum = y[c] + inc;
+            y_lo[c] = inc - (sum - y[c]);
+            y[c] = sum;
+        }
+        if constexpr (CHECK == CHECK_EXACT) track(step_index);
+    };
+
+    constexpr int CHUNK = RESYNC / 2;
+    int i = 0, since_seed = RESYNC, row = 0;
+    int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    while (i < n_run) {
+        if (since_seed >= CHUNK) {
+            seed((double)i * hd, Er, Ei, tg);
+            since_seed = 0;
+        }
+        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
+        end = end < next_save ? end : next_save;
+        const int m = end - i;
+        int j = 0;
+        for (; j + 2 <= m; j += 2) {
+            rk4_step(i + j);
+            rk4_step(i + j + 1);
+        }
+        if (j < m) rk4_step(i + j);
+        i = end;
+        since_seed += m;
+        if (i == next_save) {
+            ++row;
+            pe = fma_(y[4], y[4], y[5] * y[5]);
+            pm.x = (pe.x > pm.x || pe.x != pe.x) ? pe.x : pm.x;  // np.max propagates NaN
+            pm.y = (pe.y > pm.y || pe.y != pe.y) ? pe.y : pm.y;
+            if constexpr (CHECK == CHECK_BLOCK) track(i - 1);
+            if constexpr (TRAJ) store_rows(A.traj + (long long)row * NC * N);
+            if (row == n_rows) {
+                store_rows(A.a_end);
+                next_save = 0x7fffffff;
+            } else {
+                next_save += se;
+            }
+        }
+    }
+    if constexpr (CHECK == CHECK_BLOCK) {
+        if (n_run > 0) track(n_run - 1);
+    }
+    A.p_end[pt[0]] = pe.x;
+    A.p_max[pt[0]] = pm.x;
+    A.first_bad[pt[0]] = bad[0];
+    if (live1) {
+        A.p_end[pt[1]] = pe.y;
+        A.p_max[pt[1]] = pm.y;
+        A.first_bad[pt[1]] = bad[1];
+    }
+}
+
+template <int NW, int CHECK, bool TRAJ>
+static hipError_t launch_pk_one(hipStream_t s, int block, const SweepArgs<float> &a) {
+    const long long lanes = (a.n_points + 1) / 2;
+    if (block == 64) {
+        hipLaunchKernelGGL((rk4_sweep_pk_kernel<NW, CHECK, TRAJ, 64>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((rk4_sweep_pk_kernel<NW, CHECK, TRAJ, 256>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int NW>
+static hipError_t launch_pk_nw(hipStream_t s, int check, int block, const SweepArgs<float> &a) {
+    const bool traj = a.traj != nullptr;
+    switch (check) {
+        case CHECK_NONE:
+            return traj ? launch_pk_one<NW, CHECK_NONE, true>(s, block, a) : launch_pk_one<NW, CHECK_NONE, false>(s, block, a);
+        case CHECK_BLOCK:
+            return traj ? launch_pk_one<NW, CHECK_BLOCK, true>(s, block, a) : launch_pk_one<NW, CHECK_BLOCK, false>(s, block, a);
+        default:
+            return traj ? launch_pk_one<NW, CHECK_EXACT, true>(s, block, a) : launch_pk_one<NW, CHECK_EXACT, false>(s, block, a);
+    }
+}
+
+static hipError_t launch_sweep_pk(hipStream_t s, int n_waves, int check, int block, const SweepArgs<float> &a) {
+    if (a.n_points == 0) return hipSuccess;
+    return n_waves == 4 ? launch_pk_nw<4>(s, check, block, a) : launch_pk_nw<6>(s, check, block, a);
+}
+
+}  // namespace psa

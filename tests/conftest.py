@@ -64,4 +64,4 @@ def rel_err(got, ref):
 # Tolerances of record (DESIGN.md section "Parity"):
 RTOL_F64 = 1e-9          # north-star: final amplitudes and linear gain within 1e-9 relative (measured ~1e-12)
 ATOL_DB = 5e-9           # = 10*log10(1 + 1e-9): the same bound expressed on gain in dB
-RTOL_F32 = 1e-3          # build-defined (no fp32 reference exists); measured ~4e-4 at 1e4 steps
+RTOL_F32 = 1e-4          # build-defined (no fp32 reference exists); measured <= 5e-5 from 1e4 to 1e6 steps (Kahan state)

@@ -4,7 +4,7 @@ produced by the reference itself.
 
 Tolerances (north-star: float64 within 1e-9 relative on final amplitudes and gain):
   RTOL_F64 = 1e-9 elementwise on A_end / |A3|^2 / linear gain;  ATOL_DB = 5e-9 dB on gain in dB
-  (= 10*log10(1 + 1e-9)).  Measured agreement is ~1e-12.  float32: RTOL_F32 = 1e-3 (build-defined).
+  (= 10*log10(1 + 1e-9)).  Measured agreement is ~1e-12.  float32: RTOL_F32 = 1e-4 (build-defined).
 """
 import numpy as np
 import pytest
@@ -227,7 +227,64 @@ def test_float32_variant_within_build_defined_tolerance(oracle):
     assert rel_err(got["a_end"].astype(complex), ref["a_end"]) < RTOL_F32
     assert rel_err(got["p_max"].astype(float), ref["p_max"]) < RTOL_F32
     gd = 10 * np.log10(got["p_max"].astype(float) / 1e-5) - 10 * np.log10(ref["p_max"] / 1e-5)
-    assert np.max(np.abs(gd)) < 2e-3                             # dB
+    assert np.max(np.abs(gd)) < 5e-4                             # dB
+
+
+def test_float32_at_config4_step_count(oracle):
+    """BASELINE config 4 runs 1e6 z-steps in float32.  Without the compensated state update the error grows ~n
+    (5e-3 at 1e6 steps); with it the run must stay inside RTOL_F32 against float64 (GPU, 384 points) and against the
+    oracle (4 points at full length)."""
+    N, n = 384, 1_000_000
+    db = np.linspace(-0.02, 0.02, N)
+    a0 = _a0([0.1, 0.1, 1e-7, 1e-7])
+    kw = dict(n_steps=n, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    r64 = nat.sweep_host(db, **kw)
+    r32 = nat.sweep_host(db, dtype=np.float32, **kw)
+    assert rel_err(r32["a_end"].astype(complex), r64["a_end"]) < RTOL_F32
+    assert rel_err(r32["p_max"].astype(float), r64["p_max"]) < RTOL_F32
+    pick = np.array([0, 100, 200, 383])
+    ref = oracle.sweep(db[pick], z_max=1000.0, n=n, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    assert rel_err(r64["a_end"][pick], ref["a_end"]) < RTOL_F64
+    assert rel_err(r32["a_end"][pick].astype(complex), ref["a_end"]) < RTOL_F32
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 128, 1001])
+def test_float32_packed_two_points_per_lane_matches_scalar_float32(oracle, N):
+    """PSA_OPT_F32_PACKED (v_pk_fma_f32, points 2i and 2i+1 share a lane) runs the same float32 algorithm as the
+    one-point-per-lane kernel: they must agree to float32 rounding, odd N and per-point arguments included."""
+    rng = np.random.default_rng(N)
+    db = rng.uniform(-0.05, 0.05, N)
+    gam = rng.uniform(0.008, 0.014, N)
+    al = rng.uniform(0.0, 2e-4, N)
+    a0 = np.sqrt(rng.uniform([0.3, 0.3, 1e-6, 1e-6], [0.6, 0.6, 1e-4, 1e-4], (N, 4))) * np.exp(1j * rng.uniform(-3, 3, (N, 4)))
+    kw = dict(n_steps=2000, z_max=200.0, save_every=10, gamma=gam, alpha=al, a0=a0, dtype=np.float32, want_traj=(N <= 7),
+              exact_step=True)
+    sc = nat.sweep_host(db, extra_flags=nat.OPT_F32_SCALAR, **kw)
+    pk = nat.sweep_host(db, extra_flags=nat.OPT_F32_PACKED, **kw)
+    ref = oracle.sweep(db, z_max=200.0, n=2000, save_every=10, gamma=gam, alpha=al, a0=a0)
+    assert rel_err(pk["a_end"].astype(complex), sc["a_end"].astype(complex)) < 2e-5
+    assert rel_err(pk["p_max"].astype(float), sc["p_max"].astype(float)) < 2e-5
+    assert rel_err(pk["a_end"].astype(complex), ref["a_end"]) < RTOL_F32
+    assert np.array_equal(pk["first_bad_step"], sc["first_bad_step"]) and (pk["first_bad_step"] == -1).all()
+    if N <= 7:
+        assert pk["traj"].shape == sc["traj"].shape == (N, 201, 4)
+        assert rel_err(pk["traj"].astype(complex), sc["traj"].astype(complex)) < 2e-5
+    # failure tracking per packed half: make exactly one point of a pair blow up
+    if N >= 2:
+        g2 = gam.copy()
+        g2[1] = 40.0
+        b = nat.sweep_host(db, n_steps=200, z_max=20.0, save_every=10, gamma=g2, alpha=al, a0=a0, dtype=np.float32,
+                           extra_flags=nat.OPT_F32_PACKED, exact_step=True)
+        assert b["first_bad_step"][1] >= 0 and b["first_bad_step"][0] == -1 and np.isfinite(b["p_max"][0])
+
+
+def test_float32_six_wave_packed_matches_scalar(oracle):
+    db = np.linspace(-0.04, 0.04, 65)
+    a06 = np.sqrt(np.array([0.5, 0.4, 1e-5, 1e-5, 3e-5, 2e-6])).astype(complex)
+    kw = dict(n_steps=1000, z_max=100.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a06, dbeta2=0.5 * db, dtype=np.float32)
+    sc = nat.sweep_host(db, extra_flags=nat.OPT_F32_SCALAR, **kw)
+    pk = nat.sweep_host(db, extra_flags=nat.OPT_F32_PACKED, **kw)
+    assert rel_err(pk["a_end"].astype(complex), sc["a_end"].astype(complex)) < 2e-5
 
 
 def test_six_wave_kernel_vs_oracle_and_reduction(oracle):

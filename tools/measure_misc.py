@@ -34,3 +34,10 @@ for name, kw in (("f32 4-wave", dict(dtype=np.float32)), ("f64 6-wave", dict(dbe
     a = a0 if "4-wave" in name else np.concatenate([a0, np.sqrt([2e-5, 1e-6])])
     best = min(nat.sweep_host(db, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a, **kw)["elapsed_ms"] for _ in range(3))
     print(f"{name}: N={N} n=10000 kernel {best:.2f} ms -> {N*1e4/best/1e6:.1f} G steps/s = {a.size*N*1e4/best/1e6:.1f} G upd/s")
+
+for Nf in (65536, 131072, 1048576):
+    dbf = np.linspace(-0.05, 0.05, Nf)
+    for name, fl in (("f32 scalar", nat.OPT_F32_SCALAR), ("f32 packed", nat.OPT_F32_PACKED)):
+        best = min(nat.sweep_host(dbf, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0,
+                                  dtype=np.float32, extra_flags=fl)["elapsed_ms"] for _ in range(3))
+        print(f"{name}: N={Nf} n=10000 kernel {best:.2f} ms -> {Nf*1e4/best/1e6:.1f} G steps/s = {4*Nf*1e4/best/1e6:.1f} G upd/s", flush=True)

@@ -20,6 +20,7 @@ Fixture ids follow SURVEY.md section 8(c):
   G9  failure path: FloatingPointError step index, NaN mask through the driver
   G10 dbeta producer cases (unit variants, GENERAL_TAYLOR, dS/dlambda != 0 quirk)
   G11 driver variants: km units, linear gain, non-zero input phases
+  G12 a run bundle written by the reference's io_fwm (npz + csv + json): pins the file format
 """
 from __future__ import annotations
 
@@ -365,6 +366,17 @@ def gen_g11(pool):
           km_dbeta=np.concatenate([r[2] for r in rk]))
 
 
+def gen_g12():
+    """Files written by the reference's io_fwm.save_run_bundle (tiny: 6 rows) -- pins the on-disk format."""
+    import io_fwm
+    z = np.linspace(0.0, 1.0, 6)
+    A = (np.arange(24).reshape(6, 4) + 1j * np.arange(24).reshape(6, 4)[::-1]) * 0.1
+    out = os.path.join(HERE, "G12_io_ref")
+    io_fwm.save_run_bundle(out, "run", z, A, metadata={"gamma": 0.0115, "note": "written by the reference",
+                                                        "timestamp_utc": "2026-01-01T00:00:00Z"}, overwrite=True)
+    print("  wrote G12_io_ref/run.{npz,csv,json}", flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -376,7 +388,7 @@ def main() -> None:
     with Pool(args.procs) as pool:
         for gid, fn, needs_pool in [("G1", gen_g1, False), ("G4", gen_g4, False), ("G5", gen_g5, False),
                                     ("G6", gen_g6, False), ("G7", gen_g7, False), ("G9", gen_g9, False),
-                                    ("G10", gen_g10, False), ("G2", gen_g2, True), ("G3", gen_g3, True),
+                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("G2", gen_g2, True), ("G3", gen_g3, True),
                                     ("G11", gen_g11, True), ("G8", gen_g8, True)]:
             if want(gid):
                 print(f"{gid} ... ({time.perf_counter() - t0:.0f}s)", flush=True)

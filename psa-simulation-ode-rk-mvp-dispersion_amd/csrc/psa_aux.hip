@@ -21,24 +21,24 @@ __global__ void __launch_bounds__(256) soa_to_aos_kernel(const T *__restrict__ s
     for (int c = 0; c < nc; ++c) aos[i * nc + c] = soa[(long long)c * n + i];
 }
 
-// traj SoA [rows][nc][n] -> AoS [n][rows][nc].  A 64-point x (rows*nc)-tile goes through LDS so that both
-// the global reads (n fastest) and the global writes (c fastest within a point's row) are contiguous runs.
-template <typename T>
-__global__ void __launch_bounds__(256) traj_to_aos_kernel(const T *__restrict__ soa, T *__restrict__ aos,
-                                                          long long n, long long rows, int nc) {
-    __shared__ T tile[64][65];  // [rc within chunk][point], +1 pad: conflict-free transposed reads
-    const long long p0 = (long long)blockIdx.x * 64;
-    const long long rc_total = rows * nc;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 waves
-    for (long long rc0 = (long long)blockIdx.y * 64; rc0 < rc_total; rc0 += (long long)gridDim.y * 64) {
-        for (int r = ty; r < 64; r += 4) {
-            const long long rc = rc0 + r;
-            tile[r][tx] = (rc < rc_total && p0 + tx < n) ? soa[rc * n + p0 + tx] : T(0);
+// traj device layout [rows][nw][n] of (re, im) pairs -> NumPy layout [n][rows][nw] of pairs: a 2-D transpose of
+// 16-B (f64) / 8-B (f32) elements.  A 32-point x 32-(row,wave) tile goes through LDS so that both the global reads
+// (n fastest) and the global writes ((row, wave) fastest) are contiguous runs; +1 column: conflict-free.
+template <typename P2>
+__global__ void __launch_bounds__(256) traj_to_aos_kernel(const P2 *__restrict__ soa, P2 *__restrict__ aos,
+                                                          long long n, long long rw_total) {
+    __shared__ P2 tile[32][33];
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 rows of 32 threads
+    for (long long rw0 = (long long)blockIdx.y * 32; rw0 < rw_total; rw0 += (long long)gridDim.y * 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const long long rw = rw0 + r;
+            if (rw < rw_total && p0 + tx < n) tile[r][tx] = soa[rw * n + p0 + tx];
         }
         __syncthreads();
-        for (int p = ty; p < 64; p += 4) {
-            const long long rc = rc0 + tx;
-            if (rc < rc_total && p0 + p < n) aos[(p0 + p) * rc_total + rc] = tile[tx][p];
+        for (int p = ty; p < 32; p += 8) {
+            const long long rw = rw0 + tx;
+            if (rw < rw_total && p0 + p < n) aos[(p0 + p) * rw_total + rw] = tile[tx][p];
         }
         __syncthreads();
     }
@@ -59,10 +59,12 @@ static hipError_t launch_s2a(hipStream_t s, const T *soa, T *aos, long long n, i
 template <typename T>
 static hipError_t launch_t2a(hipStream_t s, const T *soa, T *aos, long long n, long long rows, int nc) {
     if (n == 0 || rows == 0) return hipSuccess;
-    const long long chunks = (rows * nc + 63) / 64;
+    typedef T P2 __attribute__((ext_vector_type(2)));
+    const long long rw_total = rows * (nc / 2);
+    const long long chunks = (rw_total + 31) / 32;
     const unsigned gy = (unsigned)(chunks < 64 ? chunks : 64);
-    hipLaunchKernelGGL((traj_to_aos_kernel<T>), dim3((unsigned)((n + 63) / 64), gy), dim3(256), 0, s, soa, aos, n,
-                       rows, nc);
+    hipLaunchKernelGGL((traj_to_aos_kernel<P2>), dim3((unsigned)((n + 31) / 32), gy), dim3(256), 0, s,
+                       reinterpret_cast<const P2 *>(soa), reinterpret_cast<P2 *>(aos), n, rw_total);
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ struct SweepArgs {
     T *p_end;            // [N]
     T *p_max;            // [N]
     long long *first_bad;  // [N]
-    T *traj;             // SoA [n_saved][2*NW][N] or nullptr
+    T *traj;             // [n_saved][NW][N][2] ((re, im) pairs) or nullptr
     long long n_points;
     double z_max;
     int n_steps;
@@ -39,7 +39,7 @@ hipError_t launch_aos_to_soa_f64(hipStream_t s, const double *aos, double *soa, 
 hipError_t launch_soa_to_aos_f64(hipStream_t s, const double *soa, double *aos, long long n, int nc);
 hipError_t launch_aos_to_soa_f32(hipStream_t s, const float *aos, float *soa, long long n, int nc);
 hipError_t launch_soa_to_aos_f32(hipStream_t s, const float *soa, float *aos, long long n, int nc);
-// traj: soa [rows][nc][n] -> aos [n][rows][nc]
+// traj: device [rows][nw][n][2] -> NumPy [n][rows][nw][2]   (nc = 2*nw)
 hipError_t launch_traj_to_aos_f64(hipStream_t s, const double *soa, double *aos, long long n, long long rows, int nc);
 hipError_t launch_traj_to_aos_f32(hipStream_t s, const float *soa, float *aos, long long n, long long rows, int nc);
 hipError_t launch_yaman_rhs_f64(hipStream_t s, long long n, const double *z, const double *a, const double *gamma,

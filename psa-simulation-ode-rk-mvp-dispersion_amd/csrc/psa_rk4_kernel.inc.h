@@ -29,6 +29,11 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// (re, im) as one naturally aligned 2-element vector: 16-B (f64) / 8-B (f32) global stores
+template <typename T> struct PairOf;
+template <> struct PairOf<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
 // cos/sin of a float64 phase, delivered in the working precision.
 template <typename T> struct Phase;
 template <> struct Phase<double> {
@@ -183,10 +188,15 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     const int n_rows = A.n_steps / se;                                 // saved rows after z = 0
     const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;  // the tail only matters for check_nan
 
-    if constexpr (TRAJ) {
+    // trajectory rows: device layout [row][wave][N][2] -- each lane stores one (re, im) pair = 16 B (f64), so a wave
+    // instruction writes 1 KiB contiguously (the widest coalesced store; half the store instructions of per-component rows)
+    using Pair = typename PairOf<T>::type;
+    auto store_traj_row = [&](const int r) {
+        Pair *dst = reinterpret_cast<Pair *>(A.traj) + (long long)r * NW * N + idx;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) A.traj[(long long)c * N + idx] = y[c];
-    }
+        for (int j = 0; j < NW; ++j) dst[(long long)j * N] = Pair{y[2 * j], y[2 * j + 1]};
+    };
+    if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
@@ -356,11 +366,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
             if constexpr (CHECK == CHECK_BLOCK) {
                 if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i - 1;
             }
-            if constexpr (TRAJ) {
-                T *dst = A.traj + (long long)row * NC * N + idx;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) dst[(long long)c * N] = y[c];
-            }
+            if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {  // A[-1]: the last saved row, not necessarily z_max (R8)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];

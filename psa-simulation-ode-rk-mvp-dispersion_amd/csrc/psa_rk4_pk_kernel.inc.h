@@ -84,7 +84,15 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     const int se = A.save_every;
     const int n_rows = A.n_steps / se;
     const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;
-    if constexpr (TRAJ) store_rows(A.traj);
+    auto store_traj_row = [&](const int r) {  // [row][wave][N][2]: one (re, im) pair per point
+        f32x2 *dst = reinterpret_cast<f32x2 *>(A.traj) + (long long)r * NW * N;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            dst[(long long)j * N + pt[0]] = (f32x2){y[2 * j].x, y[2 * j + 1].x};
+            if (live1) dst[(long long)j * N + pt[1]] = (f32x2){y[2 * j].y, y[2 * j + 1].y};
+        }
+    };
+    if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) store_rows(A.a_end);
 
     auto rk4_step = [&](const int step_index) {  // integrators.py:54-59, low storage: y, y_stage, accumulator
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
             pm.x = (pe.x > pm.x || pe.x != pe.x) ? pe.x : pm.x;  // np.max propagates NaN
             pm.y = (pe.y > pm.y || pe.y != pe.y) ? pe.y : pm.y;
             if constexpr (CHECK == CHECK_BLOCK) track(i - 1);
-            if constexpr (TRAJ) store_rows(A.traj + (long long)row * NC * N);
+            if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {
                 store_rows(A.a_end);
                 next_save = 0x7fffffff;

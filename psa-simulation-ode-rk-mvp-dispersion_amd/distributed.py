@@ -145,6 +145,7 @@ class DeviceSweep:
         self.alpha = torch.tensor([float(alpha)], **f64)
         self.a0_soa = torch.tensor(np.stack([a0.real, a0.imag], 1).reshape(-1, 1), **f64).contiguous()   # [8][1]
         self.record = torch.zeros((record_rows(4), self.n_local), **f64)
+        self.traj = None    # optional [n_saved][4][n_local][2] trajectory buffer (enable_trajectory)
         self.flags = (_native.BCAST_GAMMA | _native.BCAST_ALPHA | _native.BCAST_A0 | int(extra_flags)
                       | (_native.OPT_CHECK_NAN if check_nan else 0) | (_native.OPT_EXACT_STEP if exact_step else 0))
 
@@ -158,7 +159,14 @@ class DeviceSweep:
                              d_dbeta=self.dbeta.data_ptr(), d_dbeta2=0, d_gamma=self.gamma.data_ptr(),
                              d_alpha=self.alpha.data_ptr(), d_a0_soa=self.a0_soa.data_ptr(), flags=self.flags,
                              d_a_end_soa=base, d_p_end=base + 8 * n * es, d_p_max=base + 9 * n * es,
-                             d_first_bad=base + 10 * n * es, d_traj_soa=0)
+                             d_first_bad=base + 10 * n * es,
+                             d_traj_soa=(self.traj.data_ptr() if self.traj is not None else 0))
+
+    def enable_trajectory(self) -> int:
+        """Allocate the trajectory buffer [n_saved][n_waves][n_local][2] ((re, im) pairs) in HBM; returns its bytes."""
+        n_saved = self.n_steps // self.save_every + 1
+        self.traj = torch.empty((n_saved, self.n_waves, self.n_local, 2), dtype=torch.float64, device=self.device)
+        return self.traj.numel() * self.traj.element_size()
 
     def gather(self, group=None) -> torch.Tensor:
         """One all_gather of the record over the process group -> (world, rows, n_local) on this GPU."""

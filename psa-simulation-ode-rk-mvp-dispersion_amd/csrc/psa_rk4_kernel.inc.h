@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     int row = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
     while (i < n_run) {
-        if (since_seed >= CHUNK) {     // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
+        if (since_seed >= RESYNC) {    // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
             const double z = (double)i * hd;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {

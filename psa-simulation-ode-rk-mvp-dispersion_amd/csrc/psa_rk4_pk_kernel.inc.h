@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     int i = 0, since_seed = RESYNC, row = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
     while (i < n_run) {
-        if (since_seed >= CHUNK) {
+        if (since_seed >= RESYNC) {
             seed((double)i * hd, Er, Ei, tg);
             since_seed = 0;
         }

@@ -101,3 +101,19 @@ def test_host_entry_points_report_missing_device_not_a_fallback():
     assert e.value.code == -7 and "no CPU fallback" in str(e.value)
     with pytest.raises(nat.PsaNativeError):
         nat.gain_summary_host(np.ones(4), None, 1.0)
+
+
+def test_bench_and_entry_scripts_import_on_a_cpu_box():
+    """bench.py / __graft_entry__.py must at least parse and expose their contract without a GPU."""
+    import ast
+    import subprocess
+    import sys
+    for name in ("bench.py", "__graft_entry__.py"):
+        ast.parse(open(os.path.join(ROOT, name), encoding="utf-8").read())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.build) and callable(mod.smoke)

@@ -303,6 +303,19 @@ def test_six_wave_kernel_vs_oracle_and_reduction(oracle):
     assert rel_err(got6["a_end"][:, :4], got4["a_end"]) < 1e-12 and np.all(got6["a_end"][:, 4:] == 0)
 
 
+def test_six_wave_trajectory_rows(oracle):
+    a06 = np.sqrt(np.array([0.5, 0.4, 1e-5, 1e-5, 3e-5, 2e-6])) * np.exp(1j * np.array([0.0, 0.3, 0.1, -0.2, 0.5, 1.0]))
+    db, db2 = np.array([0.011, -0.02, 0.0]), np.array([-0.004, 0.015, 0.03])
+    got = nat.sweep_host(db, n_steps=333, z_max=33.3, save_every=4, gamma=0.0115, alpha=1.15e-4, a0=a06, dbeta2=db2,
+                         want_traj=True, exact_step=True)
+    assert got["traj"].shape == (3, 333 // 4 + 1, 6)
+    for i in range(3):
+        z, A, bad = oracle.integrate(a06, z_max=33.3, n=333, save_every=4, gamma=0.0115, alpha=1.15e-4, dbeta=db[i],
+                                     dbeta2=db2[i])
+        assert rel_err(got["traj"][i], A) < RTOL_F64 and bad == -1
+    assert np.array_equal(got["traj"][:, -1], got["a_end"])
+
+
 # ---- BASELINE.json full sizes: size-independent properties + sampled oracle check -------------------------------------
 def _c2_inputs(N=65536):
     return np.linspace(-0.05, 0.05, N)

@@ -10,8 +10,8 @@
 // complex polynomial (no contraction to tile).  So the design rules here are
 //   * minimum DP instructions per step (298 for 4 waves; see the count in DESIGN.md),
 //   * no transcendental in the steady-state loop: E(z) = 2*gamma*exp(i*dbeta*z) is carried by a
-//     complex rotation per half step and re-seeded from an exact sincos every RESYNC steps
-//     (bounds the recurrence drift at ~1e-14, far inside the 1e-9 parity budget),
+//     complex rotation per half step and re-seeded from an exact sincos once RESYNC steps have passed
+//     (checked between 32-step chunks: every <= 96 steps; drift ~2e-14, far inside the 1e-9 parity budget),
 //   * <= 128 VGPRs so 4 waves/SIMD stay resident, all per-lane arrays statically indexed,
 //   * wave-uniform control flow only (save stride, resync and NaN tracking never diverge),
 //   * SoA global layout: every load/store instruction of a wave is one contiguous 512-B run.
@@ -37,7 +37,7 @@ template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_
 // cos/sin of a float64 phase, delivered in the working precision.
 template <typename T> struct Phase;
 template <> struct Phase<double> {
-    static constexpr int RESYNC = 64;  // steps between exact re-seeds of the rotation recurrence
+    static constexpr int RESYNC = 64;  // steps after which the rotation recurrence is re-seeded exactly
     static __device__ __forceinline__ void eval(double ph, double &c, double &s) { sincos(ph, &s, &c); }
 };
 template <> struct Phase<float> {

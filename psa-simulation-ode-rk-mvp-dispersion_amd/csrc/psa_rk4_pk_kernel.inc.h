@@ -6,7 +6,7 @@
 // register pair turns every instruction of the step into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
 // instruction count advances twice the points.  Same algorithm and arithmetic as the scalar float32 kernel
 // (classic low-storage RK4 on the un-fused RHS with a compensated state update, phase factor re-seeded from a
-// float64-reduced sincos every <= 16 steps), so the two agree to rounding.
+// float64-reduced sincos every <= 24 steps), so the two agree to rounding.
 #pragma once
 #include "psa_rk4_kernel.inc.h"
 

@@ -49,20 +49,21 @@ PEAK_FP64_VALU_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GH
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(target_seconds: float = 12.0) -> dict:
+def cpu_baseline(target_seconds: float = 10.0) -> dict:
     """The oracle's C port (OpenMP over points, all host cores) on a bounded sample of the SAME workload:
-    P points x 100 000 steps, P sized so the run takes ~target_seconds.  Plus the structurally faithful NumPy
-    per-point restatement (the reference's own loop shape) on a tiny sample, for the like-for-like figure."""
+    P points x 100 000 steps, P sized from a one-round probe so the run takes ~target_seconds of wall time
+    (= target_seconds x cores of CPU work).  Plus the structurally faithful NumPy per-point restatement (the
+    reference's own loop shape) on a tiny sample, for the like-for-like figure."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     a0 = np.sqrt(P_IN).astype(complex)
     cores = O.max_threads()
     O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)  # warm
     t = time.perf_counter()
-    O.sweep(np.linspace(*DBETA_RANGE, cores), z_max=Z_MAX, n=N_ZSTEPS // 10, save_every=SAVE_EVERY, gamma=GAMMA,
+    O.sweep(np.linspace(*DBETA_RANGE, cores), z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA,
             alpha=ALPHA, a0=a0, threads=cores)
-    probe = (time.perf_counter() - t) * 10.0                      # est. seconds for `cores` points at full length
-    pts = max(cores, int(cores * max(1.0, target_seconds / max(probe, 1e-3))))
+    probe = time.perf_counter() - t                               # one point per core at full length
+    pts = max(cores, min(1 << 16, int(cores * max(1.0, target_seconds / max(probe, 1e-3)))))
     db = np.linspace(*DBETA_RANGE, pts)
     t = time.perf_counter()
     O.sweep(db, z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)

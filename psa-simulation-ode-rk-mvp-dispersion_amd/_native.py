@@ -99,7 +99,8 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise NativeUnavailableError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
-                "(or `make -C psa-simulation-ode-rk-mvp-dispersion_amd/csrc`). There is no CPU fallback.")
+                "(or `make -C psa-simulation-ode-rk-mvp-dispersion_amd/csrc`). There is no CPU fallback: "
+                "the sweep only runs in the HIP library.")
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:  # missing libamdhip64 etc.

@@ -117,3 +117,17 @@ def test_bench_and_entry_scripts_import_on_a_cpu_box():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert callable(mod.build) and callable(mod.smoke)
+
+
+def test_missing_shared_library_is_a_loud_error(monkeypatch, tmp_path):
+    """No libpsa_hip.so => NativeUnavailableError naming the build command -- never a silent CPU path."""
+    monkeypatch.setattr(nat, "_LIB", None)
+    monkeypatch.setattr(nat, "LIB_PATH", str(tmp_path / "libpsa_hip.so"))
+    with pytest.raises(nat.NativeUnavailableError, match="no CPU fallback"):
+        nat.sweep_host(np.zeros(3), n_steps=1, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=np.ones(4, complex))
+    from psa_amd import config, simulation
+    from psa_amd.phase_matching import PhaseMatchingConfig
+    with pytest.raises(nat.NativeUnavailableError):
+        simulation.run_single_simulation(config.custom_simulation_config(z_max=1.0, dz=0.1), gamma=1.0, alpha=0.0,
+                                         omega=[1.0] * 4, p_in=[1, 1, 0, 0],
+                                         phase_matching_cfg=PhaseMatchingConfig(method="provided", provided_delta_beta=0.0))

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     auto store_traj_row = [&](const int r) {
         Pair *dst = reinterpret_cast<Pair *>(A.traj) + (long long)r * NW * N + idx;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) dst[(long long)j * N] = Pair{y[2 * j], y[2 * j + 1]};
+        for (int j = 0; j < NW; ++j) __builtin_nontemporal_store(Pair{y[2 * j], y[2 * j + 1]}, dst + (long long)j * N);
     };
     if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) {

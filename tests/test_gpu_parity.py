@@ -390,3 +390,40 @@ def test_config4_shard_shape_float32(oracle):
     ref = oracle.sweep(db[pick].astype(np.float64), z_max=20.0, n=n, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
     assert rel_err(got["a_end"][pick].astype(complex), ref["a_end"]) < RTOL_F32
     assert (got["first_bad_step"] == -1).all() and got["a_end"].dtype == np.complex64
+
+
+def test_randomized_differential_against_oracle(oracle):
+    """60 seeded random configurations: point count, step count, save stride (below / at / above the 32-step chunk and
+    the 64-step re-seed period), check mode, trajectory on/off, 4 or 6 waves, broadcast or per-point gamma/alpha/A0."""
+    rng = np.random.default_rng(20261004)
+    strides = [1, 2, 3, 7, 10, 31, 32, 33, 63, 64, 65, 100, 257, 1000]
+    for case in range(60):
+        N = int(rng.integers(1, 200))
+        n = int(rng.integers(1, 700))
+        se = int(rng.choice(strides))
+        nw = int(rng.choice([4, 6]))
+        check, exact = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        traj = bool(rng.integers(0, 2)) and (n // se + 1) * N < 50_000
+        L = float(rng.uniform(5.0, 60.0))
+        db = rng.uniform(-0.08, 0.08, N)
+        db2 = rng.uniform(-0.08, 0.08, N) if nw == 6 else None
+        gamma = rng.uniform(5e-3, 2e-2, N) if rng.integers(0, 2) else float(rng.uniform(5e-3, 2e-2))
+        alpha = rng.uniform(0, 3e-4, N) if rng.integers(0, 2) else float(rng.choice([0.0, 1.15e-4]))
+        amp = np.sqrt(rng.uniform(1e-6, 0.8, (N, nw))) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, nw)))
+        a0 = amp if rng.integers(0, 2) else amp[0]
+        tag = f"case {case}: N={N} n={n} se={se} nw={nw} check={check} exact={exact} traj={traj}"
+        ref = oracle.sweep(db, z_max=L, n=n, save_every=se, check_nan=check, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2)
+        got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2,
+                             check_nan=check, exact_step=exact, want_traj=traj)
+        assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64, tag
+        assert rel_err(got["p_end"], ref["p_end"]) < RTOL_F64 and rel_err(got["p_max"], ref["p_max"]) < RTOL_F64, tag
+        assert np.array_equal(got["first_bad_step"], ref["first_bad_step"]) and (got["first_bad_step"] == -1).all(), tag
+        if traj:
+            i = int(rng.integers(0, N))
+            g_i = gamma[i] if np.ndim(gamma) else gamma
+            al_i = alpha[i] if np.ndim(alpha) else alpha
+            a_i = a0[i] if a0.ndim == 2 else a0
+            z, A, _ = oracle.integrate(a_i, z_max=L, n=n, save_every=se, check_nan=check, gamma=g_i, alpha=al_i,
+                                       dbeta=db[i], dbeta2=(db2[i] if nw == 6 else 0.0))
+            assert got["traj"].shape == (N, n // se + 1, nw), tag
+            assert rel_err(got["traj"][i], A) < RTOL_F64, tag

@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two processes, ``gloo`` backend, rendezvous on 127.0.0.1.
+"""The N > 1 path on CPU: two and four processes, ``gloo`` backend, rendezvous on 127.0.0.1.
 
 The shard / pack / all_gather / unpack logic is what is under test; the local executor is injected (the CPU
 oracle), because the product executor is the HIP kernel and needs a GPU.  The result gathered by every rank must
@@ -51,14 +51,14 @@ def _worker(rank, world, port, n_points, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_points", [64, 37, 1])
-def test_two_rank_gloo_sweep_equals_unsharded(tmp_path, oracle, n_points):
-    world = 2
+@pytest.mark.parametrize("world,n_points", [(2, 64), (2, 37), (2, 1), (4, 37), (4, 3)])
+def test_multi_rank_gloo_sweep_equals_unsharded(tmp_path, oracle, world, n_points):
     mp.spawn(_worker, args=(world, _free_port(), n_points, str(tmp_path)), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
-    r1 = np.load(tmp_path / "rank1.npz")
-    for k in ("a_end", "p_end", "p_max", "bad", "b_a_end"):
-        assert np.array_equal(r0[k], r1[k], equal_nan=True), k        # every rank holds the full result
+    for r in range(1, world):
+        rr = np.load(tmp_path / f"rank{r}.npz")
+        for k in ("a_end", "p_end", "p_max", "bad", "b_a_end"):
+            assert np.array_equal(r0[k], rr[k], equal_nan=True), (r, k)   # every rank holds the full result
     ref = oracle.sweep(r0["db"], z_max=30.0, n=300, save_every=7, gamma=r0["gam"], alpha=1e-4, a0=r0["a0"])
     assert np.array_equal(r0["a_end"], ref["a_end"], equal_nan=True)
     assert np.array_equal(r0["p_max"], ref["p_max"], equal_nan=True)

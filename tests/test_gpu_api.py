@@ -232,3 +232,31 @@ def test_grid_scan_rows_equal_the_1d_driver(golden):
     iy, ix = grid["best_index"]
     assert grid["best_gain"] == np.nanmax(grid["gain"]) == grid["gain"][iy, ix]
     assert grid["n_finite"] == int(np.isfinite(grid["gain"]).sum())
+
+
+def test_config3_full_grid_through_the_grid_driver(oracle):
+    """BASELINE config 3 as SURVEY 8(d) defines it: 1024 x 1024 grid (pump-2 wavelength x signal wavelength),
+    lambda_p1 = 1550 nm, dispersion D = 0.1 / S = 0.02, SYMMETRIC_EVEN (2, 4), P = (0.1, 0.1, 1e-7, 1e-7) W,
+    L = 1000 m, 100 000 z-steps, float64 -- one launch of 1 048 576 points (~1 s).  Sampled points against the oracle."""
+    lam2 = np.linspace(1552e-9, 1562e-9, 1024)
+    lam3 = np.linspace(1540e-9, 1565e-9, 1024)
+    om = frequency_plan.plan_from_wavelengths(1550e-9, 1558e-9, 1540e-9)
+    sp = frequency_plan.infer_symmetry_from_omegas(*om)
+    d = dispersion.dispersion_params_from_D_S(frequency_plan.lambda_from_omega(sp.omega_c), 0.1, 0.02, 0,
+                                              D_units="ps/nm/km", S_units="ps/nm^2/km", dSdlmbd_units="ps/nm^3/km",
+                                              omega_ref=sp.omega_c)
+    p_in = np.array([0.1, 0.1, 1e-7, 1e-7])
+    cfg = config.custom_simulation_config(z_max=1000.0, dz=0.01)
+    grid = scan_mismtach.scan_gain_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=lam2, lambda_signal_m=lam3, gamma=0.0115,
+                                        alpha=1.15e-4, p_in=p_in, dispersion=d, gain_unit="linear")
+    assert grid["gain"].shape == (1024, 1024) and grid["n_finite"] == 1024 * 1024
+    res = grid["result"]
+    assert res.n_steps == 100_000 and (res.first_bad_step == -1).all()
+    rng = np.random.default_rng(33)
+    pick = rng.choice(1024 * 1024, 24, replace=False)
+    db = grid["dbeta"].reshape(-1)[pick]
+    ref = oracle.sweep(db, z_max=1000.0, n=100_000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=np.sqrt(p_in).astype(complex))
+    assert rel_err(res.a_end[pick], ref["a_end"]) < RTOL_F64
+    np.testing.assert_allclose(grid["gain"].reshape(-1)[pick], ref["p_max"] / p_in[2], rtol=RTOL_F64)
+    iy, ix = grid["best_index"]
+    assert grid["gain"][iy, ix] == grid["gain"].max() > 1.0

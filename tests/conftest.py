@@ -17,6 +17,25 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_native_built() -> None:
+    """A fresh checkout has no libpsa_hip.so (build artefacts are not tracked).  hipcc cross-compiles gfx950 without a
+    GPU, so build it here if it is missing -- the suite must not depend on `__graft_entry__.build()` having run first."""
+    so = os.path.join(ROOT, "psa-simulation-ode-rk-mvp-dispersion_amd", "libpsa_hip.so")
+    if os.path.exists(so):
+        return
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        return  # the tests that need the library will say so loudly
+    subprocess.run(["make", "-C", os.path.join(ROOT, "psa-simulation-ode-rk-mvp-dispersion_amd", "csrc"), "-j4",
+                    f"HIPCC={hipcc if os.path.exists(hipcc) else shutil.which('hipcc')}"], check=False,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+_ensure_native_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (selected with -m gpu on the GPU box)")
 

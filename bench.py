@@ -59,11 +59,12 @@ def cpu_baseline(target_seconds: float = 10.0) -> dict:
     a0 = np.sqrt(P_IN).astype(complex)
     cores = O.max_threads()
     O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)  # warm
+    probe_pts = 4 * cores
     t = time.perf_counter()
-    O.sweep(np.linspace(*DBETA_RANGE, cores), z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA,
+    O.sweep(np.linspace(*DBETA_RANGE, probe_pts), z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA,
             alpha=ALPHA, a0=a0, threads=cores)
-    probe = time.perf_counter() - t                               # one point per core at full length
-    pts = max(cores, min(1 << 16, int(cores * max(1.0, target_seconds / max(probe, 1e-3)))))
+    probe = time.perf_counter() - t                               # four points per core at full length
+    pts = max(cores, min(1 << 16, int(probe_pts * max(1.0, target_seconds / max(probe, 1e-3)))))
     db = np.linspace(*DBETA_RANGE, pts)
     t = time.perf_counter()
     O.sweep(db, z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)

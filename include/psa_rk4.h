@@ -64,6 +64,10 @@ extern "C" {
 #define PSA_OPT_LDS_STAGING  (1u << 10)  /* keep y / y_stage / k-accumulator in LDS instead of VGPRs (the layout
                                             the north-star sketches; slower -- kept for the A/B in DESIGN.md)    */
 #define PSA_OPT_BLOCK64      (1u << 11)  /* 64-thread workgroups (one wave) instead of 256                       */
+#define PSA_OPT_LOSSLESS     (1u << 14)  /* the caller promises alpha == 0 for EVERY point: use the instantiation without
+                                            the -alpha/2 terms (the reference's own `alpha == 0.0` branch,
+                                            yaman_model.py:130-131; -10 % instructions).  The host-buffer entry points
+                                            set it themselves when alpha is a broadcast 0; `_dev` callers pass it.    */
 #define PSA_OPT_F32_SCALAR   (1u << 12)  /* float32 only: force one sweep point per lane                          */
 #define PSA_OPT_F32_PACKED   (1u << 13)  /* float32 only: force two points per lane (v_pk_fma_f32 packed math);
                                             this is also the default whenever n_points >= 2                      */

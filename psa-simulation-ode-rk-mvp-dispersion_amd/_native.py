@@ -32,6 +32,7 @@ OPT_LDS_STAGING = 1 << 10
 OPT_BLOCK64 = 1 << 11
 OPT_F32_SCALAR = 1 << 12
 OPT_F32_PACKED = 1 << 13
+OPT_LOSSLESS = 1 << 14
 
 # every symbol the header declares, with (restype, argtypes)
 _P = C.c_void_p

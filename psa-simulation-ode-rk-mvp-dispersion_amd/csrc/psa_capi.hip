@@ -86,9 +86,9 @@ psa::SweepArgs<T> make_args(int n_waves, int64_t n_points, int64_t n_steps, doub
 
 template <typename T> struct Launch;
 template <> struct Launch<double> {
-    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t /*flags*/,
+    static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
                             const psa::SweepArgs<double> &a) {
-        return psa::launch_sweep_f64(s, nw, chk, lds, blk, a);
+        return psa::launch_sweep_f64(s, nw, chk, lds, blk, (flags & PSA_OPT_LOSSLESS) != 0, a);
     }
     static hipError_t a2s(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_aos_to_soa_f64(s, a, b, n, nc); }
     static hipError_t s2a(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_soa_to_aos_f64(s, a, b, n, nc); }
@@ -98,7 +98,9 @@ template <> struct Launch<float> {
     static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
                             const psa::SweepArgs<float> &a) {
         const int pack = (flags & PSA_OPT_F32_PACKED) ? 1 : ((flags & PSA_OPT_F32_SCALAR) ? 0 : -1);
-        return psa::launch_sweep_f32(s, nw, chk, lds, blk, pack, a);
+        // the packed kernel has no lossless form: with the promise given, prefer it only when packing was forced
+        const bool lossless = (flags & PSA_OPT_LOSSLESS) != 0;
+        return psa::launch_sweep_f32(s, nw, chk, lds, blk, pack, lossless && pack == 0, a);
     }
     static hipError_t a2s(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_aos_to_soa_f32(s, a, b, n, nc); }
     static hipError_t s2a(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_soa_to_aos_f32(s, a, b, n, nc); }
@@ -153,6 +155,7 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
         if (te > 4.0e18L) return fail(PSA_E_TOO_LARGE, "trajectory buffer too large");
         traj_elems = N * (size_t)n_saved * (size_t)nc;
     }
+    if ((flags & PSA_BCAST_ALPHA) && alpha[0] == T(0)) flags |= PSA_OPT_LOSSLESS;   // the reference's alpha == 0.0 branch
     const size_t n_gamma = (flags & PSA_BCAST_GAMMA) ? 1 : N;
     const size_t n_alpha = (flags & PSA_BCAST_ALPHA) ? 1 : N;
     const size_t n_a0 = (flags & PSA_BCAST_A0) ? 1 : N;

@@ -30,8 +30,10 @@ struct SweepArgs {
 enum CheckMode : int { CHECK_NONE = 0, CHECK_BLOCK = 1, CHECK_EXACT = 2 };
 
 // launchers (defined in psa_rk4_f64.hip / psa_rk4_f32.hip)
-hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<double> &a);
-hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack,
+// lossless: the caller promises alpha == 0 for every point -> instantiation without the loss links
+hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, bool lossless,
+                            const SweepArgs<double> &a);
+hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack, bool lossless,
                             const SweepArgs<float> &a);  // pack: 1 two points/lane, 0 one, -1 auto
 
 // aux kernels (psa_aux.hip)

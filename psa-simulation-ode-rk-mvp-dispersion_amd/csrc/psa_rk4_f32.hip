@@ -6,10 +6,10 @@
 #include "psa_rk4_pk_kernel.inc.h"
 
 namespace psa {
-hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack,
+hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack, bool lossless,
                             const SweepArgs<float> &a) {
     const bool use_pack = !lds && (pack == 1 || (pack < 0 && a.n_points >= 2));
     if (use_pack) return launch_sweep_pk(s, n_waves, check, block, a);
-    return launch_sweep_t<float>(s, n_waves, check, lds, block, a);
+    return launch_sweep_t<float>(s, n_waves, check, lds, block, lossless, a);
 }
 }  // namespace psa

@@ -2,7 +2,8 @@
 #include "psa_rk4_kernel.inc.h"
 
 namespace psa {
-hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, const SweepArgs<double> &a) {
-    return launch_sweep_t<double>(s, n_waves, check, lds, block, a);
+hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, bool lossless,
+                            const SweepArgs<double> &a) {
+    return launch_sweep_t<double>(s, n_waves, check, lds, block, lossless, a);
 }
 }  // namespace psa

@@ -60,7 +60,9 @@ template <> struct Phase<float> {
 //   pumps:     F = 2*gamma*exp(+i dbeta z) * (A_s A_i)                        (yaman_model.py:174,177-178)
 //   sidebands: F = 2*gamma*exp(-i dbeta z) * (A_p1 A_p2)                      (yaman_model.py:175,180-181)
 // 64 DP instructions for NW = 4 either way (p: 8, S/g_j: 8, two products: 8, two F: 8, eight 4-deep chains: 32).
-template <typename T, int NW, bool FUSED>
+// LOSS = false is the reference's own `alpha == 0.0` branch (_linear_loss_terms returns zeros, yaman_model.py:130-131):
+// the -alpha/2 links disappear from all 2*NW chains (8 instructions per evaluation for 4 waves).
+template <typename T, int NW, bool FUSED, bool LOSS = true>
 __device__ __forceinline__ void yaman_stage(const T (&a)[2 * NW], const T (&base)[2 * NW],
                                             const T (&Er)[(NW - 2) / 2], const T (&Ei)[(NW - 2) / 2], const T g,
                                             const T tg, const T ha, T (&out)[2 * NW]) {
@@ -75,8 +77,11 @@ __device__ __forceinline__ void yaman_stage(const T (&a)[2 * NW], const T (&base
 #pragma unroll
     for (int j = 0; j < NW; ++j) gj[j] = fma_(-g, p[j], gs);  // c*gamma * f_j
 
-    // first link of each chain: (ha * component) [+ base]
-    auto lin = [&](const int c) -> T { return FUSED ? fma_(ha, a[c], base[c]) : ha * a[c]; };
+    // first two links of each chain: gsig * v  +  [ha * component]  [+ base]
+    auto link = [&](const T gsig, const T v, const int c) -> T {
+        if constexpr (LOSS) return fma_(gsig, v, FUSED ? fma_(ha, a[c], base[c]) : ha * a[c]);
+        else return FUSED ? fma_(gsig, v, base[c]) : gsig * v;
+    };
 
     const T x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3];
     const T q12r = fma_(x1, x2, -(y1 * y2)), q12i = fma_(x1, y2, y1 * x2);  // A1*A2
@@ -99,25 +104,25 @@ __device__ __forceinline__ void yaman_stage(const T (&a)[2 * NW], const T (&base
         const T Fsi = fma_(Er[pr], q12i, -(Ei[pr] * q12r));
         const T gS = gj[2 + 2 * pr], gI = gj[3 + 2 * pr];
         // signal: (ha + i gS) A_s + i conj(A_i) Fs
-        out[cs] = fma_(yi, Fsr, fma_(-xi, Fsi, fma_(-gS, ys, lin(cs))));
-        out[cs + 1] = fma_(xi, Fsr, fma_(yi, Fsi, fma_(gS, xs, lin(cs + 1))));
+        out[cs] = fma_(yi, Fsr, fma_(-xi, Fsi, link(-gS, ys, cs)));
+        out[cs + 1] = fma_(xi, Fsr, fma_(yi, Fsi, link(gS, xs, cs + 1)));
         // idler:  (ha + i gI) A_i + i conj(A_s) Fs
-        out[cs + 2] = fma_(ys, Fsr, fma_(-xs, Fsi, fma_(-gI, yi, lin(cs + 2))));
-        out[cs + 3] = fma_(xs, Fsr, fma_(ys, Fsi, fma_(gI, xi, lin(cs + 3))));
+        out[cs + 2] = fma_(ys, Fsr, fma_(-xs, Fsi, link(-gI, yi, cs + 2)));
+        out[cs + 3] = fma_(xs, Fsr, fma_(ys, Fsi, link(gI, xi, cs + 3)));
     }
     // pump1: (ha + i g1) A1 + i conj(A2) Fp ;  pump2: (ha + i g2) A2 + i conj(A1) Fp
-    out[0] = fma_(y2, Fpr, fma_(-x2, Fpi, fma_(-gj[0], y1, lin(0))));
-    out[1] = fma_(x2, Fpr, fma_(y2, Fpi, fma_(gj[0], x1, lin(1))));
-    out[2] = fma_(y1, Fpr, fma_(-x1, Fpi, fma_(-gj[1], y2, lin(2))));
-    out[3] = fma_(x1, Fpr, fma_(y1, Fpi, fma_(gj[1], x2, lin(3))));
+    out[0] = fma_(y2, Fpr, fma_(-x2, Fpi, link(-gj[0], y1, 0)));
+    out[1] = fma_(x2, Fpr, fma_(y2, Fpi, link(gj[0], x1, 1)));
+    out[2] = fma_(y1, Fpr, fma_(-x1, Fpi, link(-gj[1], y2, 2)));
+    out[3] = fma_(x1, Fpr, fma_(y1, Fpi, link(gj[1], x2, 3)));
 }
 
 // plain dA/dz (used by the LDS-staged A/B variant, which keeps k1..k4 as such)
-template <typename T, int NW>
+template <typename T, int NW, bool LOSS = true>
 __device__ __forceinline__ void yaman_rhs(const T (&a)[2 * NW], const T (&Er)[(NW - 2) / 2],
                                           const T (&Ei)[(NW - 2) / 2], const T g, const T tg, const T ha,
                                           T (&k)[2 * NW]) {
-    yaman_stage<T, NW, false>(a, a, Er, Ei, g, tg, ha, k);
+    yaman_stage<T, NW, false, LOSS>(a, a, Er, Ei, g, tg, ha, k);
 }
 
 // (Er,Ei) *= (rc,rs)
@@ -143,7 +148,7 @@ __device__ __forceinline__ bool any_nonfinite(const T (&y)[NC]) {
 // ds_read/ds_write_b64 touches 64 consecutive 8-byte words: conflict-free).  It exists for the A/B in DESIGN.md
 // section 5: the register-resident form wins because the LDS round trips buy nothing (no data is shared
 // between lanes) and cost issue slots next to an already saturated FP64 pipe.
-template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK, bool LDS = false>
+template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK, bool LDS = false, bool LOSS = true>
 __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) {
     constexpr int NC = 2 * NW;
     constexpr int NP = (NW - 2) / 2;
@@ -252,22 +257,22 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     // 2*d*gamma*exp(i*dbeta*z): on entry at z_step, on exit rotated to z_step + h.
     auto rk4_step_reg = [&](const int step_index) {
         T Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
-        yaman_stage<T, NW, true>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);  // Y2 = y + d k1
+        yaman_stage<T, NW, true, LOSS>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);  // Y2 = y + d k1
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h/2
-        yaman_stage<T, NW, true>(Y2, y, Er, Ei, g_d, tg_d, ha_d, Y3);  // Y3 = y + d k2
+        yaman_stage<T, NW, true, LOSS>(Y2, y, Er, Ei, g_d, tg_d, ha_d, Y3);  // Y3 = y + d k2
         T E2r[NP], E2i[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             E2r[p] = Er[p] + Er[p];
             E2i[p] = Ei[p] + Ei[p];
         }
-        yaman_stage<T, NW, true>(Y3, y, E2r, E2i, g_h, tg_h, ha_h, Y4);  // Y4 = y + h k3
+        yaman_stage<T, NW, true, LOSS>(Y3, y, E2r, E2i, g_h, tg_h, ha_h, Y4);  // Y4 = y + h k3
 #pragma unroll
         for (int c = 0; c < NC; ++c) t[c] = fma_(T(2), Y3[c], fma_(T(-4), y[c], Y2[c])) + Y4[c];
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h
-        yaman_stage<T, NW, true>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);  // D = t + d k4
+        yaman_stage<T, NW, true, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);  // D = t + d k4
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
         if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step (a select, not a branch)
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
     for (int c = 0; c < NC; ++c) y_lo[c] = T{};
     auto rk4_step_classic = [&](const int step_index) {
         T k[NC], ys[NC], acc[NC];
-        yaman_rhs<T, NW>(y, Er, Ei, g, tg, ha, k);  // k1 at z
+        yaman_rhs<T, NW, LOSS>(y, Er, Ei, g, tg, ha, k);  // k1 at z
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             acc[c] = k[c];
@@ -291,13 +296,13 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h/2
-        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k2
+        yaman_rhs<T, NW, LOSS>(ys, Er, Ei, g, tg, ha, k);  // k2
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             acc[c] = fma_(T(2), k[c], acc[c]);
             ys[c] = fma_(hh, k[c], y[c]);
         }
-        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k3
+        yaman_rhs<T, NW, LOSS>(ys, Er, Ei, g, tg, ha, k);  // k3
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             acc[c] = fma_(T(2), k[c], acc[c]);
@@ -305,7 +310,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);  // z + h
-        yaman_rhs<T, NW>(ys, Er, Ei, g, tg, ha, k);  // k4
+        yaman_rhs<T, NW, LOSS>(ys, Er, Ei, g, tg, ha, k);  // k4
         // compensated (Kahan) state update: keeps the part of the increment that y + inc rounds away (see the
         // packed kernel); without it float32 drifts ~n * ulp and misses its 1e-3 tolerance at 1e6 steps.
 #pragma unroll
@@ -385,8 +390,18 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) 
 }
 
 template <typename T, int NW, int CHECK, bool TRAJ>
-static hipError_t launch_one(hipStream_t s, int block, bool lds, const SweepArgs<T> &a) {
+static hipError_t launch_one(hipStream_t s, int block, bool lds, bool lossless, const SweepArgs<T> &a) {
     if (a.n_points == 0) return hipSuccess;
+    if (lossless && !lds) {  // alpha == 0 for every point (caller's promise): the 8 loss links per RHS are compiled out
+        if (block == 64) {
+            hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 64, false, false>), dim3((unsigned)((a.n_points + 63) / 64)),
+                               dim3(64), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 256, false, false>),
+                               dim3((unsigned)((a.n_points + 255) / 256)), dim3(256), 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (lds) {  // A/B variant: one wave per workgroup, 5 * 2*NW * 64 * sizeof(T) bytes of LDS (20 KB for f64, 4 waves)
         const unsigned grid = (unsigned)((a.n_points + 63) / 64);
         hipLaunchKernelGGL((rk4_sweep_kernel<T, NW, CHECK, TRAJ, 64, true>), dim3(grid), dim3(64), 0, s, a);
@@ -403,26 +418,26 @@ static hipError_t launch_one(hipStream_t s, int block, bool lds, const SweepArgs
 }
 
 template <typename T, int NW>
-static hipError_t launch_nw(hipStream_t s, int check, int block, bool lds, const SweepArgs<T> &a) {
+static hipError_t launch_nw(hipStream_t s, int check, int block, bool lds, bool lossless, const SweepArgs<T> &a) {
     const bool traj = a.traj != nullptr;
     switch (check) {
         case CHECK_NONE:
-            return traj ? launch_one<T, NW, CHECK_NONE, true>(s, block, lds, a)
-                        : launch_one<T, NW, CHECK_NONE, false>(s, block, lds, a);
+            return traj ? launch_one<T, NW, CHECK_NONE, true>(s, block, lds, lossless, a)
+                        : launch_one<T, NW, CHECK_NONE, false>(s, block, lds, lossless, a);
         case CHECK_BLOCK:
-            return traj ? launch_one<T, NW, CHECK_BLOCK, true>(s, block, lds, a)
-                        : launch_one<T, NW, CHECK_BLOCK, false>(s, block, lds, a);
+            return traj ? launch_one<T, NW, CHECK_BLOCK, true>(s, block, lds, lossless, a)
+                        : launch_one<T, NW, CHECK_BLOCK, false>(s, block, lds, lossless, a);
         default:
-            return traj ? launch_one<T, NW, CHECK_EXACT, true>(s, block, lds, a)
-                        : launch_one<T, NW, CHECK_EXACT, false>(s, block, lds, a);
+            return traj ? launch_one<T, NW, CHECK_EXACT, true>(s, block, lds, lossless, a)
+                        : launch_one<T, NW, CHECK_EXACT, false>(s, block, lds, lossless, a);
     }
 }
 
 template <typename T>
-static hipError_t launch_sweep_t(hipStream_t s, int n_waves, int check, bool lds, int block,
+static hipError_t launch_sweep_t(hipStream_t s, int n_waves, int check, bool lds, int block, bool lossless,
                                  const SweepArgs<T> &a) {
-    if (n_waves == 4) return launch_nw<T, 4>(s, check, block, lds, a);
-    return launch_nw<T, 6>(s, check, block, lds, a);
+    if (n_waves == 4) return launch_nw<T, 4>(s, check, block, lds, lossless, a);
+    return launch_nw<T, 6>(s, check, block, lds, lossless, a);
 }
 
 }  // namespace psa

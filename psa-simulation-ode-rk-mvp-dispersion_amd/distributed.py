@@ -147,7 +147,8 @@ class DeviceSweep:
         self.record = torch.zeros((record_rows(4), self.n_local), **f64)
         self.traj = None    # optional [n_saved][4][n_local][2] trajectory buffer (enable_trajectory)
         self.flags = (_native.BCAST_GAMMA | _native.BCAST_ALPHA | _native.BCAST_A0 | int(extra_flags)
-                      | (_native.OPT_CHECK_NAN if check_nan else 0) | (_native.OPT_EXACT_STEP if exact_step else 0))
+                      | (_native.OPT_CHECK_NAN if check_nan else 0) | (_native.OPT_EXACT_STEP if exact_step else 0)
+                      | (_native.OPT_LOSSLESS if float(alpha) == 0.0 else 0))
 
     def launch(self) -> None:
         """Asynchronous: enqueue the sweep kernel on torch's current stream."""

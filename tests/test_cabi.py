@@ -35,7 +35,8 @@ def test_flag_values_match_the_header():
     for name, val in (("PSA_BCAST_GAMMA", nat.BCAST_GAMMA), ("PSA_BCAST_ALPHA", nat.BCAST_ALPHA),
                       ("PSA_BCAST_A0", nat.BCAST_A0), ("PSA_OPT_CHECK_NAN", nat.OPT_CHECK_NAN),
                       ("PSA_OPT_EXACT_STEP", nat.OPT_EXACT_STEP), ("PSA_OPT_LDS_STAGING", nat.OPT_LDS_STAGING),
-                      ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64)):
+                      ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64), ("PSA_OPT_F32_SCALAR", nat.OPT_F32_SCALAR),
+                      ("PSA_OPT_F32_PACKED", nat.OPT_F32_PACKED), ("PSA_OPT_LOSSLESS", nat.OPT_LOSSLESS)):
         m = re.search(rf"#define\s+{name}\s+\(1u\s*<<\s*(\d+)\)", src)
         assert m and (1 << int(m.group(1))) == val, name
 

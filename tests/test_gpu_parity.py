@@ -85,6 +85,25 @@ def test_lds_staged_variant_matches_register_variant(oracle):
     assert rel_err(l6["a_end"], r6["a_end"]) < RTOL_F64
 
 
+def test_lossless_instantiation_equals_the_generic_kernel_at_alpha_zero(oracle):
+    """alpha == 0 as a broadcast scalar selects the instantiation without the loss links (the reference's own
+    `alpha == 0.0` branch); a per-point array of zeros runs the generic kernel.  Same numbers, to rounding."""
+    db = np.linspace(-0.05, 0.05, 300)
+    for a0v, d2 in ((A0, None), (np.concatenate([A0, np.sqrt([2e-5, 1e-6])]), -0.5 * db)):
+        kw = dict(n_steps=3000, z_max=300.0, save_every=10, gamma=0.0115, a0=a0v, dbeta2=d2)
+        ref = oracle.sweep(db, z_max=300.0, n=3000, save_every=10, gamma=0.0115, alpha=0.0, a0=a0v, dbeta2=d2)
+        fast = nat.sweep_host(db, alpha=0.0, **kw)
+        slow = nat.sweep_host(db, alpha=np.zeros(db.size), **kw)
+        assert rel_err(fast["a_end"], ref["a_end"]) < RTOL_F64 and rel_err(slow["a_end"], ref["a_end"]) < RTOL_F64
+        assert rel_err(fast["a_end"], slow["a_end"]) < 1e-12
+        P = np.abs(fast["a_end"]) ** 2
+        np.testing.assert_allclose(P.sum(1), (np.abs(a0v) ** 2).sum(), rtol=1e-11)     # lossless: total power conserved
+    f32 = nat.sweep_host(db, alpha=0.0, dtype=np.float32, extra_flags=nat.OPT_F32_SCALAR, n_steps=3000, z_max=300.0,
+                         save_every=10, gamma=0.0115, a0=A0)
+    ref = oracle.sweep(db, z_max=300.0, n=3000, save_every=10, gamma=0.0115, alpha=0.0, a0=A0)
+    assert rel_err(f32["a_end"].astype(complex), ref["a_end"]) < RTOL_F32
+
+
 def test_empty_sweep_is_a_noop():
     got = nat.sweep_host(np.zeros(0), n_steps=10, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=A0)
     assert got["a_end"].shape == (0, 4) and got["p_max"].shape == (0,)

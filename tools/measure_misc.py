@@ -41,3 +41,9 @@ for Nf in (65536, 131072, 1048576):
         best = min(nat.sweep_host(dbf, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0,
                                   dtype=np.float32, extra_flags=fl)["elapsed_ms"] for _ in range(3))
         print(f"{name}: N={Nf} n=10000 kernel {best:.2f} ms -> {Nf*1e4/best/1e6:.1f} G steps/s = {4*Nf*1e4/best/1e6:.1f} G upd/s", flush=True)
+
+for Nl in (65536, 1048576):
+    dbl = np.linspace(-0.05, 0.05, Nl)
+    for name, al in (("alpha = 0 broadcast (lossless instantiation)", 0.0), ("alpha = zeros[N] (generic kernel)", np.zeros(Nl))):
+        best = min(nat.sweep_host(dbl, n_steps=10_000, z_max=1000.0, save_every=10, gamma=0.0115, alpha=al, a0=a0)["elapsed_ms"] for _ in range(3))
+        print(f"lossless A/B N={Nl}: {name}: {best:.2f} ms -> {Nl*1e4/best/1e6:.1f} G steps/s", flush=True)

@@ -260,3 +260,25 @@ def test_config3_full_grid_through_the_grid_driver(oracle):
     np.testing.assert_allclose(grid["gain"].reshape(-1)[pick], ref["p_max"] / p_in[2], rtol=RTOL_F64)
     iy, ix = grid["best_index"]
     assert grid["gain"][iy, ix] == grid["gain"].max() > 1.0
+
+
+def test_the_ctypes_stub_printed_in_integration_md_runs(golden):
+    """INTEGRATION.md shows the binding a maintainer of the reference would add (psa_hip.py).  Execute exactly that
+    text (library path substituted) and check it against golden G8, so the document cannot rot."""
+    import os
+    import re
+    import types
+    import psa_amd._native as nat
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    block = re.search(r"```python\n(# psa_hip.py.*?)```", doc, re.S).group(1)
+    block = block.replace("/path/to/psa-simulation-ode-rk-mvp-dispersion_amd/libpsa_hip.so", nat.LIB_PATH)
+    stub = types.ModuleType("psa_hip_stub")
+    exec(compile(block, "INTEGRATION.md:psa_hip.py", "exec"), stub.__dict__)
+    g = golden("G8")
+    a_end, p_end, p_max, bad, traj = stub.rk4_sweep(g["dbeta257"], float(g["gamma"]), float(g["alphas"][1]),
+                                                    np.sqrt(g["p_in"]).astype(complex), 1000.0, 10_000, 10)
+    assert rel_err(a_end, g["n1e4_a1_A_end"]) < RTOL_F64 and rel_err(p_max, g["n1e4_a1_p_max"]) < RTOL_F64
+    assert (bad == -1).all() and traj is None
+    a1, _, _, b1, t1 = stub.rk4_sweep([0.013], 0.0115, 1.15e-4, np.sqrt(g["p_in"]).astype(complex), 100.5, 1005, 10, want_traj=True)
+    assert t1.shape == (1, 101, 4) and np.array_equal(t1[0, -1], a1[0])

@@ -282,3 +282,30 @@ def test_the_ctypes_stub_printed_in_integration_md_runs(golden):
     assert (bad == -1).all() and traj is None
     a1, _, _, b1, t1 = stub.rk4_sweep([0.013], 0.0115, 1.15e-4, np.sqrt(g["p_in"]).astype(complex), 100.5, 1005, 10, want_traj=True)
     assert t1.shape == (1, 101, 4) and np.array_equal(t1[0, -1], a1[0])
+
+
+def test_device_entry_point_can_be_captured_into_a_graph_and_replayed(oracle):
+    """include/psa_rk4.h: the `_dev` entry points neither allocate nor synchronise.  Capture one sweep launch into a
+    HIP graph (through torch.cuda.CUDAGraph), change the inputs in place, replay, and compare with the oracle."""
+    import torch
+    from psa_amd.distributed import DeviceSweep, unpack_records
+    a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
+    db1 = np.linspace(-0.05, 0.05, 500)
+    db2 = np.linspace(0.02, -0.03, 500)
+    ds = DeviceSweep(db1, n_steps=800, z_max=80.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0,
+                     device=torch.device("cuda", 0))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ds.launch()                                   # warm-up outside capture (module load)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ds.launch()
+    for db in (db1, db2):
+        ds.dbeta.copy_(torch.as_tensor(db, device=ds.device))
+        ds.record.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        a, pe, pm, fb = unpack_records(ds.record.cpu().numpy()[None], db.size, 1, 4)
+        ref = oracle.sweep(db, z_max=80.0, n=800, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+        assert rel_err(a, ref["a_end"]) < RTOL_F64 and rel_err(pm, ref["p_max"]) < RTOL_F64 and (fb == -1).all()

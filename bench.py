@@ -8,8 +8,8 @@
 One bench "step" = one pass of the hot path over one batch: BASELINE config 2 per GPU -- 65 536 dbeta sweep
 points x 4 fields x 100 000 z-steps, float64, dbeta = linspace(-0.05, 0.05), gamma = 0.0115, alpha = 1.15e-4,
 P = (0.5, 0.5, 1e-5, 1e-5) W, L = 1000 m, save_every = 10, check_nan on (SURVEY 8d "C2").  Inputs are resident in
-HBM before the timed region; a step is the kernel launch on the rank's shard plus, for N > 1, the single RCCL
-all_gather of the 88 B/point output record.  Weak scaling: every rank owns 65 536 points (rank r gets the r-th
+HBM before the timed region; a step is the sweep kernel on the rank's shard, the on-device gain reduction (per-point gain
++ argmax, the sweep drivers' summary) and, for N > 1, the single RCCL all_gather of the 88 B/point output record.  Weak scaling: every rank owns 65 536 points (rank r gets the r-th
 contiguous block of the global linspace).
 
 Prints ONE JSON line on rank 0 (metric/value/unit/... + "roofline" + "cpu_baseline").
@@ -199,6 +199,7 @@ def main() -> None:
         sweep.launch()
         if ev1 is not None:
             ev1.record()
+        sweep.summarize(float(P_IN[2]), mode="max", gain_db=True)   # the drivers' per-point gain + argmax, on device
         return sweep.gather() if use_dist else None
 
     for _ in range(args.warmup):
@@ -235,9 +236,15 @@ def main() -> None:
         ref = O.sweep(dbeta[pick], z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA,
                       a0=np.sqrt(P_IN).astype(complex), threads=4)
         err = float(np.max(np.abs(res.a_end[pick] - ref["a_end"]) / np.abs(ref["a_end"])))
-        verify = {"points_checked_vs_oracle": int(pick.size), "max_rel_err_a_end": err,
-                  "all_finite": bool((res.first_bad_step == -1).all())}
-        if not (err < 1e-9 and verify["all_finite"]):
+        gain_dev = sweep.gain.cpu().numpy()
+        gain_ref = O.gain_from_summary(ref["p_max"], ref["first_bad_step"], P_IN[2], "db")
+        best_i, n_fin = (int(v) for v in sweep.best.cpu().numpy())
+        err_gain = float(np.max(np.abs(gain_dev[pick] - gain_ref)))
+        verify = {"points_checked_vs_oracle": int(pick.size), "max_rel_err_a_end": err, "max_err_gain_db": err_gain,
+                  "all_finite": bool((res.first_bad_step == -1).all()), "best_gain_db": float(sweep.best_gain.item()),
+                  "best_index": best_i}
+        if not (err < 1e-9 and err_gain < 5e-9 and verify["all_finite"] and n_fin == PTS_PER_GPU
+                and best_i == int(np.argmax(gain_dev))):
             raise SystemExit(f"bench result failed its parity guard: {verify}")
 
     if rank == 0:

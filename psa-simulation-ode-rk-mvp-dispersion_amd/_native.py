@@ -246,3 +246,15 @@ def gain_summary_host(p_metric, first_bad_step, p0_sig: float, *, gain_db: bool 
                                       _ptr(gain), C.cast(C.byref(bi), _P), C.cast(C.byref(bg), _P),
                                       C.cast(C.byref(nf), _P)))
     return gain, int(bi.value), float(bg.value), int(nf.value)
+
+
+def gain_summary_device(*, stream: int, n_points: int, d_p_metric: int, d_first_bad: int, p0_sig: float, gain_db: bool,
+                        d_gain: int, d_best_index: int, d_best_gain: int, d_n_finite: int, d_workspace: int) -> None:
+    """Asynchronous gain reduction on device pointers (ints) -- see psa_gain_summary_f64_dev."""
+    _check(lib().psa_gain_summary_f64_dev(stream or None, int(n_points), d_p_metric or None, d_first_bad or None,
+                                          float(p0_sig), int(bool(gain_db)), d_gain or None, d_best_index or None,
+                                          d_best_gain or None, d_n_finite or None, d_workspace or None))
+
+
+def gain_summary_workspace_bytes(n_points: int) -> int:
+    return int(lib().psa_gain_summary_workspace_bytes(int(n_points)))

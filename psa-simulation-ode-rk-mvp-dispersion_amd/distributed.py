@@ -163,6 +163,23 @@ class DeviceSweep:
                              d_first_bad=base + 10 * n * es,
                              d_traj_soa=(self.traj.data_ptr() if self.traj is not None else 0))
 
+    def summarize(self, p0_sig: float, *, mode: str = "max", gain_db: bool = True) -> None:
+        """Enqueue the gain reduction of the sweep drivers (scan_mismtach.py:376-389 + argmax) on the same stream:
+        fills ``self.gain`` (n_local,), ``self.best`` = [best_index, n_finite] (int64) and ``self.best_gain`` (1,)."""
+        if not hasattr(self, "gain"):
+            f64 = dict(dtype=torch.float64, device=self.device)
+            self.gain = torch.empty(self.n_local, **f64)
+            self.best = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self.best_gain = torch.zeros(1, **f64)
+            self._ws = torch.empty(_native.gain_summary_workspace_bytes(self.n_local), dtype=torch.uint8, device=self.device)
+        es, n, base = self.record.element_size(), self.n_local, self.record.data_ptr()
+        row = 9 if mode == "max" else 8                      # p_sig_max | p_sig_end row of the record
+        _native.gain_summary_device(stream=torch.cuda.current_stream(self.device).cuda_stream, n_points=n,
+                                    d_p_metric=base + row * n * es, d_first_bad=base + 10 * n * es, p0_sig=p0_sig,
+                                    gain_db=gain_db, d_gain=self.gain.data_ptr(), d_best_index=self.best.data_ptr(),
+                                    d_best_gain=self.best_gain.data_ptr(), d_n_finite=self.best.data_ptr() + 8,
+                                    d_workspace=self._ws.data_ptr())
+
     def enable_trajectory(self) -> int:
         """Allocate the trajectory buffer [n_saved][n_waves][n_local][2] ((re, im) pairs) in HBM; returns its bytes."""
         n_saved = self.n_steps // self.save_every + 1

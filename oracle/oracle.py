@@ -191,3 +191,39 @@ def np_integrate(a0, *, z_max, dz, save_every, check_nan, gamma, alpha, dbeta):
             y_out[k] = y
             k += 1
     return z_out[:k], y_out[:k]
+
+
+def np_rhs6(z, a, gamma, alpha, dbeta1, dbeta2):
+    """Independent NumPy statement of the BUILD-DEFINED 6-wave model (no reference counterpart), waves
+    [p1, p2, s1, i1, s2, i2]:
+
+        dA_j/dz = -alpha/2 A_j + i*gamma*(|A_j|^2 + 2*sum_{k != j} |A_k|^2) A_j + 2i*gamma*M_j
+        M_p1 = conj(A_p2) * (A_s1 A_i1 e^{+i db1 z} + A_s2 A_i2 e^{+i db2 z})      M_p2: p1 <-> p2
+        M_s1 = conj(A_i1) * A_p1 A_p2 e^{-i db1 z}    M_i1 = conj(A_s1) * A_p1 A_p2 e^{-i db1 z}     (pair 2 alike)
+
+    Same conventions as the 4-wave reference model (yaman_model.py:148-151, :174-186); with pair 2 dark it IS that model.
+    """
+    a = np.asarray(a, dtype=np.complex128)
+    P = np.abs(a) ** 2
+    f = P + 2.0 * (P.sum() - P)
+    e1, e2 = np.exp(1j * dbeta1 * z), np.exp(1j * dbeta2 * z)
+    pumps = a[2] * a[3] * e1 + a[4] * a[5] * e2
+    q12 = a[0] * a[1]
+    M = np.array([np.conj(a[1]) * pumps, np.conj(a[0]) * pumps,
+                  np.conj(a[3]) * q12 * np.conj(e1), np.conj(a[2]) * q12 * np.conj(e1),
+                  np.conj(a[5]) * q12 * np.conj(e2), np.conj(a[4]) * q12 * np.conj(e2)])
+    return (-0.5 * alpha) * a + 1j * gamma * f * a + 2j * gamma * M
+
+
+def np_integrate6(a0, *, z_max, n, gamma, alpha, dbeta1, dbeta2):
+    """Plain RK4 (integrators.py:25-61) on np_rhs6 over np.linspace(0, z_max, n + 1); returns the final state."""
+    zg = np.linspace(0.0, z_max, n + 1)
+    y = np.array(a0, dtype=np.complex128)
+    for i in range(n):
+        z, h = zg[i], zg[i + 1] - zg[i]
+        k1 = np_rhs6(z, y, gamma, alpha, dbeta1, dbeta2)
+        k2 = np_rhs6(z + 0.5 * h, y + 0.5 * h * k1, gamma, alpha, dbeta1, dbeta2)
+        k3 = np_rhs6(z + 0.5 * h, y + 0.5 * h * k2, gamma, alpha, dbeta1, dbeta2)
+        k4 = np_rhs6(z + h, y + h * k3, gamma, alpha, dbeta1, dbeta2)
+        y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    return y

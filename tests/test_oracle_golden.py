@@ -148,3 +148,23 @@ def test_six_wave_reduces_to_four_wave(golden, oracle):
     r6 = oracle.sweep(db, z_max=1000.0, n=10_000, save_every=10, gamma=0.0115, alpha=1.15e-4,
                       a0=np.concatenate([a0, [0, 0]]), dbeta2=db * 0.37)
     assert rel_err(r6["a_end"][:, :4], r4["a_end"]) < 1e-12 and np.all(r6["a_end"][:, 4:] == 0)
+
+
+def test_six_wave_c_oracle_matches_an_independent_numpy_statement(oracle):
+    """The 6-wave model has no reference: pin the C oracle to a second, independently written NumPy form of the same
+    equations (oracle.np_rhs6), over random states, and check both collapse to the 4-wave golden G5 when pair 2 is dark."""
+    rng = np.random.default_rng(6)
+    for _ in range(5):
+        a0 = np.sqrt(rng.uniform(1e-6, 0.6, 6)) * np.exp(1j * rng.uniform(-3, 3, 6))
+        g, al, d1, d2 = rng.uniform(5e-3, 2e-2), rng.choice([0.0, 2e-4]), rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05)
+        want = oracle.np_integrate6(a0, z_max=40.0, n=400, gamma=g, alpha=al, dbeta1=d1, dbeta2=d2)
+        z, A, bad = oracle.integrate(a0, z_max=40.0, n=400, save_every=400, gamma=g, alpha=al, dbeta=d1, dbeta2=d2)
+        assert bad == -1 and rel_err(A[-1], want) < 1e-12
+
+
+def test_np_rhs6_reduces_to_the_four_wave_reference_rhs(golden, oracle):
+    g = golden("G5")
+    for i in range(0, 64, 5):
+        a6 = np.concatenate([g["a"][i], [0, 0]])
+        r = oracle.np_rhs6(g["z"][i], a6, g["gamma"][i], g["alpha"][i], g["dbeta"][i], 0.123)
+        assert np.max(np.abs(r[:4] - g["rhs"][i])) <= 1e-14 * np.max(np.abs(g["rhs"][i])) and np.all(r[4:] == 0)

@@ -446,3 +446,32 @@ def test_randomized_differential_against_oracle(oracle):
                                        dbeta=db[i], dbeta2=(db2[i] if nw == 6 else 0.0))
             assert got["traj"].shape == (N, n // se + 1, nw), tag
             assert rel_err(got["traj"][i], A) < RTOL_F64, tag
+
+
+def test_extreme_parameters(oracle):
+    """Corners of the input space: |dbeta*h| ~ 0.25 rad per step and dbeta*z up to ~1.2e4 rad (exercises the phase
+    recurrence and the large-argument sincos re-seed), seed powers down to 1e-24 W and exactly zero, dark pumps,
+    negative gamma, strong loss."""
+    rng = np.random.default_rng(99)
+    N = 96
+    db = np.concatenate([rng.uniform(-12.0, 12.0, N - 4), [12.0, -12.0, 0.0, 1e-12]])
+    P = np.stack([10 ** rng.uniform(-3, 0, N), 10 ** rng.uniform(-3, 0, N), 10 ** rng.uniform(-24, -3, N),
+                  10 ** rng.uniform(-24, -3, N)], 1)
+    P[0] = [0.5, 0.5, 0.0, 0.0]        # no seed at all: sidebands must stay exactly zero
+    P[1] = [0.0, 0.0, 1e-3, 1e-3]      # dark pumps
+    P[2] = [0.0, 0.7, 1e-6, 0.0]
+    a0 = np.sqrt(P) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, 4)))
+    gamma = rng.uniform(-0.02, 0.02, N)
+    alpha = 10 ** rng.uniform(-6, -2, N)
+    n, L = 50_000, 1000.0              # h = 0.02 m
+    ref = oracle.sweep(db, z_max=L, n=n, save_every=100, gamma=gamma, alpha=alpha, a0=a0)
+    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=100, gamma=gamma, alpha=alpha, a0=a0, exact_step=True)
+    assert (got["first_bad_step"] == -1).all() and (ref["first_bad_step"] == -1).all()
+    scale = np.abs(ref["a_end"]).max(axis=1, keepdims=True)
+    # per-point normalisation: a wave that is ~1e-12 of the pumps carries absolute, not relative, rounding noise
+    assert np.max(np.abs(got["a_end"] - ref["a_end"]) / scale) < RTOL_F64
+    strong = np.abs(ref["a_end"]) > 1e-6 * scale
+    assert rel_err(got["a_end"][strong], ref["a_end"][strong]) < 1e-7
+    assert np.all(got["a_end"][0, 2:] == 0) and np.all(got["a_end"][1, :2] == 0)
+    live = ref["p_max"] > 0
+    assert rel_err(got["p_max"][live], ref["p_max"][live]) < 1e-7

@@ -132,3 +132,23 @@ def test_missing_shared_library_is_a_loud_error(monkeypatch, tmp_path):
         simulation.run_single_simulation(config.custom_simulation_config(z_max=1.0, dz=0.1), gamma=1.0, alpha=0.0,
                                          omega=[1.0] * 4, p_in=[1, 1, 0, 0],
                                          phase_matching_cfg=PhaseMatchingConfig(method="provided", provided_delta_beta=0.0))
+
+
+def test_header_is_valid_c99_and_a_c_program_links_and_gets_the_documented_codes(tmp_path):
+    """The boundary is a C ABI: compile include/psa_rk4.h as strict C99, build tests/c/abi_client.c with gcc against
+    libpsa_hip.so and run it (argument validation only -- no GPU needed)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                    os.path.join(inc, "psa_rk4.h")], check=True)
+    libdir = os.path.dirname(nat.LIB_PATH)
+    exe = str(tmp_path / "abi_client")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", inc, os.path.join(ROOT, "tests", "c", "abi_client.c"),
+                    "-o", exe, "-L", libdir, "-lpsa_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "abi_client ok" in out.stdout

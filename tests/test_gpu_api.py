@@ -309,3 +309,24 @@ def test_device_entry_point_can_be_captured_into_a_graph_and_replayed(oracle):
         a, pe, pm, fb = unpack_records(ds.record.cpu().numpy()[None], db.size, 1, 4)
         ref = oracle.sweep(db, z_max=80.0, n=800, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
         assert rel_err(a, ref["a_end"]) < RTOL_F64 and rel_err(pm, ref["p_max"]) < RTOL_F64 and (fb == -1).all()
+
+
+def test_plain_c_program_drives_a_sweep_through_the_abi(tmp_path):
+    """tests/c/abi_gpu_client.c: a C99 program (no Python, no torch) runs a 257-point sweep with trajectories, the gain
+    summary and one RHS evaluation through libpsa_hip.so and checks A[-1] == last saved row."""
+    import os
+    import shutil
+    import subprocess
+    import psa_amd._native as nat
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(nat.LIB_PATH)
+    exe = str(tmp_path / "abi_gpu_client")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "abi_gpu_client.c"), "-o", exe, "-L", libdir, "-lpsa_hip", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert "abi_gpu_client ok" in out.stdout

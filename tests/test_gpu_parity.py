@@ -397,18 +397,23 @@ def test_config5_shard_shape_six_wave_sampled_parity(oracle):
     np.testing.assert_allclose((np.abs(got["a_end"]) ** 2).sum(1), P6.sum() * np.exp(-alpha * L), rtol=1e-10)
 
 
-def test_config4_shard_shape_float32(oracle):
-    """BASELINE config 4 per-GPU shard: 131 072 points, float32 (packed kernel by default); 20 000 of the 1e6
-    z-steps here (the full step count runs in test_float32_at_config4_step_count on fewer points)."""
-    N, n = 131_072, 20_000
+def test_config4_per_gpu_shard_at_full_length_float32(oracle):
+    """BASELINE config 4, one GPU's shard exactly: 131 072 sweep points x 4 fields x 1 000 000 z-steps, float32
+    (packed kernel + compensated state), ~0.7 s of kernel time.  Eight sampled points against the float64 oracle at full
+    length; every point finite; total power follows exp(-alpha L) to float32 accuracy."""
+    N, n, L, alpha = 131_072, 1_000_000, 1000.0, 1.15e-4
     rng = np.random.default_rng(44)
     db = rng.uniform(-0.02, 0.02, N).astype(np.float32)
-    a0 = _a0([0.1, 0.1, 1e-7, 1e-7])
-    got = nat.sweep_host(db, n_steps=n, z_max=20.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0, dtype=np.float32)
-    pick = rng.choice(N, 32, replace=False)
-    ref = oracle.sweep(db[pick].astype(np.float64), z_max=20.0, n=n, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
-    assert rel_err(got["a_end"][pick].astype(complex), ref["a_end"]) < RTOL_F32
+    p_in = np.array([0.1, 0.1, 1e-7, 1e-7])
+    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=_a0(p_in), dtype=np.float32)
     assert (got["first_bad_step"] == -1).all() and got["a_end"].dtype == np.complex64
+    pick = rng.choice(N, 8, replace=False)
+    ref = oracle.sweep(db[pick].astype(np.float64), z_max=L, n=n, save_every=10, gamma=0.0115, alpha=alpha, a0=_a0(p_in))
+    assert rel_err(got["a_end"][pick].astype(complex), ref["a_end"]) < RTOL_F32
+    assert rel_err(got["p_max"][pick].astype(float), ref["p_max"]) < RTOL_F32
+    P = (np.abs(got["a_end"].astype(complex)) ** 2).sum(1)
+    np.testing.assert_allclose(P, p_in.sum() * np.exp(-alpha * L), rtol=2e-5)
+    print(f"config 4 shard: kernel {got['elapsed_ms']:.1f} ms -> {4 * N * n / got['elapsed_ms'] / 1e6:.0f} G updates/s")
 
 
 def test_randomized_differential_against_oracle(oracle):

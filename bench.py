@@ -268,7 +268,10 @@ def main() -> None:
             "rk4_steps_per_s": value / N_FIELDS,
             "roofline": {
                 "kernel": "psa::rk4_sweep_kernel<double, 4, CHECK_BLOCK, false, 256>",
-                "bound": "fp64-valu",
+                "bound": "mfma",   # the contract's label for the COMPUTE roofline (enum hbm | mfma); see bound_detail
+                "bound_detail": "compute-bound on the FP64 VECTOR ALU: the kernel issues 0 MFMA instructions (elementwise "
+                                "complex recurrence, nothing to contract); MI355X FP64 vector and FP64 matrix dense peaks "
+                                "are both 78.6 TFLOP/s, so the peak is the same number either way",
                 "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_VALU_TFLOPS,
                 "flops_per_launch": FLOPS_PER_RK4_STEP * rk4_steps_per_launch,
                 "kernel_ms_avg": kern_ms,

@@ -49,7 +49,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GH
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(target_seconds: float = 10.0) -> dict:
+def cpu_baseline(target_seconds: float = 6.0) -> dict:
     """The oracle's C port (OpenMP over points, all host cores) on a bounded sample of the SAME workload:
     P points x 100 000 steps, P sized from a one-round probe so the run takes ~target_seconds of wall time
     (= target_seconds x cores of CPU work).  Plus the structurally faithful NumPy per-point restatement (the

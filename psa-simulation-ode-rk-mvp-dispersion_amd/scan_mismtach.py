@@ -6,6 +6,8 @@
   argmax-over-sweep summary -- what the reference's dead ``scan_mismatch_seeded_signal`` (:43-259) set out to do.
 * ``scan_gain_grid(...)``: the same sweep over a 2-D (pump-2 wavelength x signal wavelength) grid in one launch
   (BASELINE config 3's shape: 1024 x 1024 points); the reference has no grid builder.
+* ``scan_six_wave_grid(...)``: BASELINE config 5's shape -- a grid over the detunings (Omega1, Omega2) of two
+  signal/idler pairs sharing the two pumps, on the build-defined 6-wave model (no reference counterpart).
 
 Where the reference loops over lambda3 in Python and calls ``run_single_simulation`` per point, these drivers
 build every plan and every dbeta at once on the host (``plan_from_wavelengths_batch``,
@@ -23,7 +25,7 @@ from typing import Literal, Optional, Sequence, Tuple
 import numpy as np
 
 from .config import SimulationConfig, custom_simulation_config, n_steps_of  # noqa: F401
-from .dispersion import DispersionParams
+from .dispersion import DispersionParams, delta_beta_symmetric_array
 from .frequency_plan import plan_from_wavelengths_batch
 from .phase_matching import PhaseMatchingConfig, PhaseMatchingMethod, compute_phase_mismatch_batch
 from .simulation import _prepare, make_initial_amplitudes
@@ -314,3 +316,53 @@ def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Se
     return dict(gain=gain.reshape(lam2.size, lam3.size), dbeta=dbeta.reshape(lam2.size, lam3.size), best_index=best,
                 best_gain=(float(gain.reshape(-1)[best[0] * lam3.size + best[1]]) if best else float("nan")),
                 n_finite=int(finite.sum()), result=res)
+
+
+def scan_six_wave_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: float, Omega1: Sequence[float],
+                       Omega2: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
+                       phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
+                       even_orders: Tuple[int, ...] = (2, 4), length_unit: str = "m", gain_unit: str = "dB",
+                       gain_mode: GainMode = "max", device: int = 0) -> dict:
+    """Six waves [p1, p2, s1, i1, s2, i2]: pair k sits at omega_c +- Omega_k (omega_c, omega_d from the two pumps) and
+    has dbeta_k = sum_{n even} beta_n (Omega_k^n - omega_d^n) 2/n!  (the symmetric-even form, dispersion.py:321-372).
+    Runs the Omega1[Ny] x Omega2[Nx] grid in ONE launch of the 6-wave kernel.
+
+    p_in / phase_in: six entries.  Returns dict(gain (Ny, Nx) of signal 1 -- the kernel's summary wave --, dbeta1 (Ny,),
+    dbeta2 (Nx,), a_end (Ny, Nx, 6), first_bad_step (Ny, Nx), result=SweepResult).  The 6-wave model is build-defined:
+    with pair 2 dark every row equals the 4-wave run at dbeta1 (tested), beyond that parity is unpinned.
+    """
+    if gain_mode not in ("end", "max"):
+        raise ValueError(f"Unknown gain_mode={gain_mode!r}. Use 'end' or 'max'.")
+    unit = _norm_choice(gain_unit, "gain_unit", ("db", "linear"))
+    p0 = np.asarray(list(p_in), dtype=float)
+    if p0.shape != (6,) or not np.all(np.isfinite(p0)) or np.any(p0 < 0.0):
+        raise ValueError("p_in must hold six finite non-negative powers [p1, p2, s1, i1, s2, i2]")
+    if p0[2] <= 0.0:
+        raise ValueError("p_in[2] (signal-1 seed power) must be > 0 to define gain")
+    ph = None if phase_in is None else np.asarray(list(phase_in), dtype=float)
+    if ph is not None and (ph.shape != (6,) or not np.all(np.isfinite(ph))):
+        raise ValueError("phase_in must hold six finite phases")
+    O1, O2 = np.asarray(list(Omega1), dtype=float), np.asarray(list(Omega2), dtype=float)
+    if O1.ndim != 1 or O2.ndim != 1 or O1.size == 0 or O2.size == 0 or not (np.all(np.isfinite(O1)) and np.all(np.isfinite(O2))):
+        raise ValueError("Omega1 and Omega2 must be non-empty 1D sequences of finite detunings (rad/s)")
+    if dispersion is None:
+        raise ValueError("dispersion must be provided")
+    from .frequency_plan import omega_from_lambda
+    w1, w2 = omega_from_lambda(lambda_p1_m), omega_from_lambda(lambda_p2_m)
+    wc, wd = 0.5 * (w1 + w2), 0.5 * (w1 - w2)
+    if np.any(np.abs(O1) >= wc) or np.any(np.abs(O2) >= wc):
+        raise ValueError("|Omega| must stay below omega_c (sideband frequencies must be positive)")
+    pre = _prepare(cfg, gamma=gamma, alpha=alpha, dispersion=dispersion, phase_matching_cfg=None, beta_legacy=None,
+                   length_unit=length_unit)
+    disp_m, fiber, grid = pre["fiber"].dispersion, pre["fiber"], pre["grid"]
+    db1 = delta_beta_symmetric_array(wd, O1, disp_m, even_orders=even_orders)      # per metre
+    db2 = delta_beta_symmetric_array(wd, O2, disp_m, even_orders=even_orders)
+    D1, D2 = np.meshgrid(db1, db2, indexing="ij")
+    from .sweep import initial_amplitudes
+    res = rk4_sweep(D1.ravel(), dbeta2=D2.ravel(), z_max=fiber.length_m, dz=grid.dz_m, save_every=cfg.save_every,
+                    check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m,
+                    a0=initial_amplitudes(p0, ph), device=device)
+    gain = res.gain(p0[2], mode=gain_mode, unit=unit, device=device)
+    shape = (O1.size, O2.size)
+    return dict(gain=gain.reshape(shape), dbeta1=db1 * pre["scale"], dbeta2=db2 * pre["scale"],
+                a_end=res.a_end.reshape(shape + (6,)), first_bad_step=res.first_bad_step.reshape(shape), result=res)

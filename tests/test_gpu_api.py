@@ -371,3 +371,36 @@ def test_two_ranks_share_the_gpu_native_executor_gloo_gather(tmp_path, oracle):
                        a0=np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex))
     assert r0["a_end"].shape == (1001, 4) and rel_err(r0["a_end"], ref["a_end"]) < RTOL_F64
     assert rel_err(r0["p_max"], ref["p_max"]) < RTOL_F64 and (r0["bad"] == -1).all()
+
+
+def test_six_wave_grid_driver(golden, oracle):
+    """scan_six_wave_grid (config 5's shape, here 6 x 9): sampled points against the oracle's 6-wave statement, and the
+    reduction property -- with pair 2 dark, every column equals the 4-wave sweep at dbeta1."""
+    g = golden("G11")
+    dv = g["disp_m"]
+    d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3])
+    cfg = config.custom_simulation_config(z_max=300.0, dz=0.1)
+    O1 = np.linspace(2e12, 9e12, 6)
+    O2 = np.linspace(-8e12, -1e12, 9)
+    P6 = np.array([0.3, 0.25, 2e-6, 5e-7, 1e-6, 1e-6])
+    out = scan_mismtach.scan_six_wave_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1556e-9, Omega1=O1, Omega2=O2,
+                                           gamma=0.0115, alpha=1.0e-4, p_in=P6, dispersion=d, gain_unit="linear")
+    assert out["gain"].shape == (6, 9) and out["a_end"].shape == (6, 9, 6) and (out["first_bad_step"] == -1).all()
+    a06 = np.sqrt(P6).astype(complex)
+    for iy, ix in ((0, 0), (2, 5), (5, 8)):
+        ref = oracle.sweep(np.array([out["dbeta1"][iy]]), z_max=300.0, n=3000, save_every=10, gamma=0.0115, alpha=1.0e-4,
+                           a0=a06, dbeta2=np.array([out["dbeta2"][ix]]))
+        assert rel_err(out["a_end"][iy, ix], ref["a_end"][0]) < RTOL_F64
+        assert out["gain"][iy, ix] == pytest.approx(ref["p_max"][0] / P6[2], rel=RTOL_F64)
+    dark = P6.copy()
+    dark[4:] = 0.0
+    o2 = scan_mismtach.scan_six_wave_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1556e-9, Omega1=O1, Omega2=O2,
+                                          gamma=0.0115, alpha=1.0e-4, p_in=dark, dispersion=d, gain_unit="linear")
+    r4 = scan_mismtach.scan_dbeta_seeded_signal(cfg=cfg, delta_beta=o2["dbeta1"], gamma=0.0115, alpha=1.0e-4, p_in=dark[:4],
+                                                gain_mode="max", gain_unit="linear")
+    for ix in range(9):
+        np.testing.assert_allclose(o2["gain"][:, ix], r4["gain"], rtol=1e-11)
+    assert np.all(o2["a_end"][..., 4:] == 0)
+    with pytest.raises(ValueError):
+        scan_mismtach.scan_six_wave_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1556e-9, Omega1=O1, Omega2=O2,
+                                         gamma=0.0115, alpha=0.0, p_in=P6[:4], dispersion=d)

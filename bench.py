@@ -50,14 +50,32 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def cpu_baseline(target_seconds: float = 6.0) -> dict:
-    """The oracle's C port (OpenMP over points, all host cores) on a bounded sample of the SAME workload:
-    P points x 100 000 steps, P sized from a one-round probe so the run takes ~target_seconds of wall time
-    (= target_seconds x cores of CPU work).  Plus the structurally faithful NumPy per-point restatement (the
-    reference's own loop shape) on a tiny sample, for the like-for-like figure."""
+    """CPU legs, all on a bounded sample of the SAME workload (called BEFORE the GPU is initialised):
+      * value: the oracle's C port (OpenMP over points, all host cores), P points x 100 000 steps with P sized from a
+        probe so it takes ~target_seconds of wall time (= target_seconds x cores of CPU work);
+      * the structurally faithful NumPy per-point restatement (the reference's own loop shape) on 1 core and on every
+        core (one process per core, forked before any OpenMP thread exists), and a batched-NumPy form, for context
+        (SURVEY 8(d)(ii))."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     a0 = np.sqrt(P_IN).astype(complex)
-    cores = O.max_threads()
+    O.lib()
+    # a one-GPU box's CPU share is 16 cores (more hardware threads may be visible); PSA_BENCH_CPU_CORES overrides
+    cores = max(1, min(O.max_threads(), len(os.sched_getaffinity(0)), int(os.environ.get("PSA_BENCH_CPU_CORES", "16"))))
+    np_steps = N_ZSTEPS // 50
+    t = time.perf_counter()
+    O.np_integrate(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / N_ZSTEPS, save_every=SAVE_EVERY, check_nan=True, gamma=GAMMA,
+                   alpha=ALPHA, dbeta=0.01)
+    np_wall = time.perf_counter() - t
+    t = time.perf_counter()
+    O.np_integrate_all_cores(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / N_ZSTEPS, dbetas=np.linspace(*DBETA_RANGE, cores), procs=cores)
+    np_all_wall = time.perf_counter() - t
+    nb_pts, nb_steps = 4096, 100
+    t = time.perf_counter()
+    O.np_sweep_batched(np.linspace(*DBETA_RANGE, nb_pts), z_max=Z_MAX * nb_steps / N_ZSTEPS, n=nb_steps, gamma=GAMMA,
+                       alpha=ALPHA, a0=a0)
+    nb_wall = time.perf_counter() - t
+    # the C port last: OpenMP worker threads appear only now
     O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)  # warm
     probe_pts = 4 * cores
     t = time.perf_counter()
@@ -69,16 +87,18 @@ def cpu_baseline(target_seconds: float = 6.0) -> dict:
     t = time.perf_counter()
     O.sweep(db, z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)
     wall = time.perf_counter() - t
-    t = time.perf_counter()
-    O.np_integrate(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / N_ZSTEPS, save_every=SAVE_EVERY, check_nan=True, gamma=GAMMA,
-                   alpha=ALPHA, dbeta=0.01)
-    np_wall = time.perf_counter() - t
     return {"value": pts * N_FIELDS * N_ZSTEPS / wall, "unit": "field-point updates/s", "cores": cores, "kind": "port",
             "sample": f"{pts} sweep points x {N_FIELDS} fields x {N_ZSTEPS} z-steps of the bench workload, "
                       f"oracle/psa_oracle.c (scalar C99, OpenMP over points), {wall:.1f} s wall",
-            "numpy_restatement_1core": {"value": N_FIELDS * (N_ZSTEPS // 50) / np_wall,
-                                        "sample": f"1 point x {N_ZSTEPS // 50} z-steps, oracle.np_integrate "
-                                                  "(reference-shaped Python loop), 1 core"}}
+            "numpy_restatement_1core": {"value": N_FIELDS * np_steps / np_wall,
+                                        "sample": f"1 point x {np_steps} z-steps, oracle.np_integrate "
+                                                  "(reference-shaped Python loop), 1 core"},
+            "numpy_restatement_all_cores": {"value": cores * N_FIELDS * np_steps / np_all_wall, "cores": cores,
+                                            "sample": f"{cores} points x {np_steps} z-steps, one process per core "
+                                                      "(multiprocessing.Pool, pool start-up included)"},
+            "numpy_batched_1core": {"value": nb_pts * N_FIELDS * nb_steps / nb_wall,
+                                    "sample": f"{nb_pts} points x {nb_steps} z-steps, oracle.np_sweep_batched "
+                                              "(arrays over sweep points)"}}
 
 
 def measured_traffic() -> dict | None:
@@ -170,6 +190,10 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # CPU legs first: they fork worker processes, which must happen before this process touches the GPU
+    cpu_leg = None
+    if world == 1 and args.mode == "summary" and not args.no_cpu_baseline and torch.cuda.device_count() > 0:
+        cpu_leg = cpu_baseline()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -284,9 +308,9 @@ def main() -> None:
             },
             "verify": verify,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if cpu_leg is not None:
+            out["cpu_baseline"] = cpu_leg
+            out["gpu_over_cpu"] = value / cpu_leg["value"]
         if use_dist:
             torch.cuda.synchronize()
         sys.stdout.flush()

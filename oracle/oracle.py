@@ -227,3 +227,45 @@ def np_integrate6(a0, *, z_max, n, gamma, alpha, dbeta1, dbeta2):
         k4 = np_rhs6(z + h, y + h * k3, gamma, alpha, dbeta1, dbeta2)
         y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
     return y
+
+
+# --------------------------------------------------------------------------
+# CPU timing helpers for bench.py's cpu_baseline: the reference-shaped loop on every core,
+# and a batched-NumPy form (arrays over sweep points) for context.
+# --------------------------------------------------------------------------
+def _np_point_job(args):
+    a0, z_max, dz, dbeta = args
+    z, A = np_integrate(a0, z_max=z_max, dz=dz, save_every=10, check_nan=True, gamma=0.0115, alpha=1.15e-4, dbeta=dbeta)
+    return A[-1]
+
+
+def np_integrate_all_cores(a0, *, z_max, dz, dbetas, procs):
+    """One reference-shaped run per process (multiprocessing.Pool), as BASELINE.md section 2 did for the reference."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(procs) as pool:
+        return pool.map(_np_point_job, [(a0, z_max, dz, float(d)) for d in dbetas])
+
+
+def np_sweep_batched(dbeta, *, z_max, n, gamma, alpha, a0):
+    """Batched NumPy RK4: the same algorithm with arrays over the sweep points (shape (4, N)); final state (N, 4)."""
+    dbeta = np.asarray(dbeta, dtype=float)
+    y = np.repeat(np.asarray(a0, dtype=np.complex128)[:, None], dbeta.size, axis=1)
+
+    def rhs(z, a):
+        P = (a.real ** 2 + a.imag ** 2)
+        f = 2.0 * P.sum(0) - P
+        e = np.exp(1j * dbeta * z)
+        q12, q34 = a[0] * a[1], a[2] * a[3]
+        fw = np.stack([np.conj(a[1]) * q34 * e, np.conj(a[0]) * q34 * e,
+                       np.conj(a[3]) * q12 * np.conj(e), np.conj(a[2]) * q12 * np.conj(e)])
+        return (-0.5 * alpha) * a + 1j * gamma * (f * a) + 2j * gamma * fw
+
+    h = z_max / n
+    for i in range(n):
+        z = i * h
+        k1 = rhs(z, y)
+        k2 = rhs(z + 0.5 * h, y + 0.5 * h * k1)
+        k3 = rhs(z + 0.5 * h, y + 0.5 * h * k2)
+        k4 = rhs(z + h, y + h * k3)
+        y = y + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    return y.T

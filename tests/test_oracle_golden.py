@@ -168,3 +168,11 @@ def test_np_rhs6_reduces_to_the_four_wave_reference_rhs(golden, oracle):
         a6 = np.concatenate([g["a"][i], [0, 0]])
         r = oracle.np_rhs6(g["z"][i], a6, g["gamma"][i], g["alpha"][i], g["dbeta"][i], 0.123)
         assert np.max(np.abs(r[:4] - g["rhs"][i])) <= 1e-14 * np.max(np.abs(g["rhs"][i])) and np.all(r[4:] == 0)
+
+
+def test_batched_numpy_form_agrees_with_the_c_oracle(oracle):
+    db = np.linspace(-0.05, 0.05, 33)
+    a0 = _a0([0.5, 0.5, 1e-5, 1e-5])
+    got = oracle.np_sweep_batched(db, z_max=50.0, n=500, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    ref = oracle.sweep(db, z_max=50.0, n=500, save_every=500, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    assert rel_err(got, ref["a_end"]) < 1e-12

@@ -404,3 +404,38 @@ def test_six_wave_grid_driver(golden, oracle):
     with pytest.raises(ValueError):
         scan_mismtach.scan_six_wave_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1556e-9, Omega1=O1, Omega2=O2,
                                          gamma=0.0115, alpha=0.0, p_in=P6[:4], dispersion=d)
+
+
+def test_concurrent_host_api_calls_from_four_threads():
+    """include/psa_rk4.h: the host-buffer entry points keep no global state (own stream + own device buffers per call).
+    Four threads sweep different inputs at the same time (ctypes drops the GIL); every result must equal the
+    sequential one bit for bit, and per-thread error strings must not leak between threads."""
+    import threading
+    import psa_amd._native as nat
+    a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
+    jobs = [dict(dbeta=np.linspace(-0.05, 0.05, 3000 + 17 * k), n_steps=4000 + 100 * k, z_max=400.0 + k, save_every=10,
+                 gamma=0.0115 + 1e-4 * k, alpha=1.15e-4) for k in range(4)]
+    run = lambda j: nat.sweep_host(j["dbeta"], n_steps=j["n_steps"], z_max=j["z_max"], save_every=j["save_every"],  # noqa: E731
+                                   gamma=j["gamma"], alpha=j["alpha"], a0=a0)
+    sequential = [run(j) for j in jobs]
+    results, errors = [None] * 4, []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                results[k] = run(jobs[k])
+            with pytest.raises(nat.PsaNativeError) as e:       # an argument error on this thread only
+                nat.sweep_host(np.zeros(3), n_steps=0, z_max=1.0, save_every=1, gamma=1.0, alpha=0.0, a0=a0)
+            assert e.value.code == -3
+        except BaseException as exc:  # noqa: BLE001
+            errors.append((k, exc))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for seq, par in zip(sequential, results):
+        assert np.array_equal(seq["a_end"], par["a_end"]) and np.array_equal(seq["p_max"], par["p_max"])
+        assert np.array_equal(seq["first_bad_step"], par["first_bad_step"])

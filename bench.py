@@ -299,6 +299,10 @@ def main() -> None:
                 "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_VALU_TFLOPS,
                 "flops_per_launch": FLOPS_PER_RK4_STEP * rk4_steps_per_launch,
                 "kernel_ms_avg": kern_ms,
+                # 301.8 FP64 wave-instructions per z-step per wave (SQ_INSTS_VALU, profiles/README.md) x 4 issue cycles:
+                # the clock the chip would need if the FP64 pipe never idled = a LOWER bound on the clock it held.  Boxes of
+                # the pool differ by ~10 % here (DVFS / silicon), which moves `frac` with no change in the code.
+                "fp64_issue_ghz_equiv": 301.8 * 4 * N_ZSTEPS / (kern_ms * 1e-3) / 1e9,
                 "traffic": None if traffic is None else traffic.get("bytes_per_launch"),
                 "traffic_source": None if traffic is None else traffic.get("source"),
                 "note": "elementwise complex recurrence: no MFMA, ~2e-4 B per update -> FP64 vector issue is the binding "

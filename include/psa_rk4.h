@@ -46,7 +46,8 @@ extern "C" {
 #define PSA_E_NULLPTR    -6   /* a required pointer is NULL                          */
 #define PSA_E_DEVICE     -7   /* device index out of range / no gfx950 device        */
 #define PSA_E_DBETA2     -8   /* n_waves == 6 needs dbeta2; n_waves == 4 forbids it  */
-#define PSA_E_TOO_LARGE  -9   /* trajectory buffer size overflows int64              */
+#define PSA_E_TOO_LARGE  -9   /* trajectory does not fit (int64 / device memory), or n_points exceeds the launch grid */
+#define PSA_E_DBETA_MODEL -10 /* dbeta producer: unknown method, bad even_orders / max_order / beta count  */
 
 /* ---- flags ----------------------------------------------------------------- */
 /* broadcast: the array has ONE entry used for every sweep point */
@@ -68,6 +69,11 @@ extern "C" {
                                             the -alpha/2 terms (the reference's own `alpha == 0.0` branch,
                                             yaman_model.py:130-131; -10 % instructions).  The host-buffer entry points
                                             set it themselves when alpha is a broadcast 0; `_dev` callers pass it.    */
+#define PSA_OPT_SPLIT_POINT  (1u << 15)  /* float64 only: force TWO LANES per sweep point (a point's waves divided between
+                                            neighbouring lanes, partial sums exchanged by DPP): halves the sequential
+                                            instruction stream per lane.  Default: chosen automatically when the sweep is
+                                            smaller than the chip (2*N lanes still get one SIMD per wave: N <= 32 768).   */
+#define PSA_OPT_ONE_LANE     (1u << 16)  /* float64 only: never split a point over two lanes                              */
 #define PSA_OPT_F32_SCALAR   (1u << 12)  /* float32 only: force one sweep point per lane                          */
 #define PSA_OPT_F32_PACKED   (1u << 13)  /* float32 only: force two points per lane (v_pk_fma_f32 packed math);
                                             this is also the default whenever n_points >= 2                      */
@@ -157,6 +163,60 @@ int psa_gain_summary_f64_dev(void *stream, int64_t n_points, const double *d_p_m
                              int64_t *d_best_index, double *d_best_gain, int64_t *d_n_finite,
                              void *d_workspace /* >= psa_gain_summary_workspace_bytes(n_points) */);
 int64_t psa_gain_summary_workspace_bytes(int64_t n_points);
+
+/* float32 sweeps (psa_rk4_sweep_f32): p_metric and the per-point gain are float, the ratio p/p0 and log10 are formed in
+ * float64; best_gain stays double. */
+int psa_gain_summary_f32(int device, int64_t n_points, const float *p_metric, const int64_t *first_bad_step,
+                         double p0_sig, int gain_db, float *gain_out, int64_t *best_index, double *best_gain,
+                         int64_t *n_finite);
+int psa_gain_summary_f32_dev(void *stream, int64_t n_points, const float *d_p_metric, const int64_t *d_first_bad_step,
+                             double p0_sig, int gain_db, float *d_gain_out, int64_t *d_best_index, double *d_best_gain,
+                             int64_t *d_n_finite, void *d_workspace);
+
+/* ---- the phase mismatch of a whole grid, produced on the device ------------------------------------------------
+ * A multi-GPU shard generates its own dbeta slice from the grid definition instead of receiving it:
+ * point i of the flattened grid lambda_p2[n2] x lambda_signal[n3] (row-major: i2 = i / n3, i3 = i % n3) gets
+ *   w_j = two_pi_c / lambda_j,  w4 = (w1 + w2) - w3                     frequency_plan.plan_from_wavelengths  :291-327
+ *   method PSA_DBETA_SYMMETRIC_EVEN: omega_c, omega_d, Omega as frequency_plan.infer_symmetry_from_omegas :215-255, then
+ *       dbeta = sum over even_orders of beta_n (Omega^n - omega_d^n) 2/n!   dispersion.delta_beta_symmetric  :321-372
+ *   method PSA_DBETA_GENERAL_TAYLOR: (beta(w3) + beta(w4)) - (beta(w1) + beta(w2)), beta(w) = sum_{n <= max_order}
+ *       beta_n (w - omega_ref)^n / n!                                        dispersion.delta_beta_from_omegas :282-318
+ * and dbeta = NaN (valid = 0) wherever the reference would raise for that point (wavelength <= 0, w4 <= 0, energy
+ * conservation beyond atol/rtol, inconsistent symmetric plan, non-finite result) -- what its sweep drivers turn into a
+ * NaN gain (scan_mismtach.py:391-392).  float64 arithmetic in the reference's operation order; the _f32 variants round
+ * the float64 result to float.
+ *   beta[n_beta]   beta_0 .. beta_{n_beta-1} per length unit (host pointer, n_beta <= 9; DispersionParams.get_beta_n)
+ *   two_pi_c       the caller's 2*pi*c (constants.c), passed so host and device divide the same double
+ *   lambda axes    device pointers (_dev) or host pointers (blocking variant); [first_index, first_index + n_points)
+ *                  is the caller's block of the flattened grid.
+ */
+#define PSA_DBETA_SYMMETRIC_EVEN 0
+#define PSA_DBETA_GENERAL_TAYLOR 1
+int psa_dbeta_grid_f64_dev(void *stream, int method, const int32_t *even_orders, int n_even_orders, int max_order,
+                           const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol,
+                           double lambda1_m, const double *d_lambda2_axis, int64_t n2, const double *d_lambda3_axis,
+                           int64_t n3, int64_t first_index, int64_t n_points, double *d_dbeta, uint8_t *d_valid_or_null);
+int psa_dbeta_grid_f32_dev(void *stream, int method, const int32_t *even_orders, int n_even_orders, int max_order,
+                           const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol,
+                           double lambda1_m, const double *d_lambda2_axis, int64_t n2, const double *d_lambda3_axis,
+                           int64_t n3, int64_t first_index, int64_t n_points, float *d_dbeta, uint8_t *d_valid_or_null);
+int psa_dbeta_grid_f64(int device, int method, const int32_t *even_orders, int n_even_orders, int max_order,
+                       const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol,
+                       double lambda1_m, const double *lambda2_axis, int64_t n2, const double *lambda3_axis, int64_t n3,
+                       int64_t first_index, int64_t n_points, double *dbeta, uint8_t *valid_or_null);
+
+/* Six-wave grid (build-defined, scan_six_wave_grid): pair k sits at omega_c +- Omega_k and has
+ * dbeta_k = delta_beta_symmetric(omega_d, Omega_k); point i of the flattened Omega1[n1] x Omega2[n2] grid gets
+ * (dbeta1, dbeta2) = (dbeta(Omega1[i / n2]), dbeta(Omega2[i % n2])). */
+int psa_dbeta_pairs_f64_dev(void *stream, const int32_t *even_orders, int n_even_orders, const double *beta, int n_beta,
+                            double omega_d, const double *d_Omega1_axis, int64_t n1, const double *d_Omega2_axis,
+                            int64_t n2, int64_t first_index, int64_t n_points, double *d_dbeta1, double *d_dbeta2);
+int psa_dbeta_pairs_f32_dev(void *stream, const int32_t *even_orders, int n_even_orders, const double *beta, int n_beta,
+                            double omega_d, const double *d_Omega1_axis, int64_t n1, const double *d_Omega2_axis,
+                            int64_t n2, int64_t first_index, int64_t n_points, float *d_dbeta1, float *d_dbeta2);
+int psa_dbeta_pairs_f64(int device, const int32_t *even_orders, int n_even_orders, const double *beta, int n_beta,
+                        double omega_d, const double *Omega1_axis, int64_t n1, const double *Omega2_axis, int64_t n2,
+                        int64_t first_index, int64_t n_points, double *dbeta1, double *dbeta2);
 
 #ifdef __cplusplus
 }

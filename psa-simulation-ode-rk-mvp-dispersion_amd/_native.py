@@ -20,7 +20,8 @@ from typing import Optional
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libpsa_hip.so")
+# PSA_HIP_LIB: developer hook to load an A/B build of the same library (tools/ab_build.sh); never a different backend
+LIB_PATH = os.environ.get("PSA_HIP_LIB") or os.path.join(_PKG_DIR, "libpsa_hip.so")
 
 # flags (mirror include/psa_rk4.h)
 BCAST_GAMMA = 1 << 0
@@ -33,6 +34,8 @@ OPT_BLOCK64 = 1 << 11
 OPT_F32_SCALAR = 1 << 12
 OPT_F32_PACKED = 1 << 13
 OPT_LOSSLESS = 1 << 14
+OPT_SPLIT_POINT = 1 << 15
+OPT_ONE_LANE = 1 << 16
 
 # every symbol the header declares, with (restype, argtypes)
 _P = C.c_void_p
@@ -53,7 +56,26 @@ _SIGS = {
     "psa_gain_summary_f64": (C.c_int, [C.c_int, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P]),
     "psa_gain_summary_f64_dev": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
     "psa_gain_summary_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "psa_gain_summary_f32": (C.c_int, [C.c_int, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P]),
+    "psa_gain_summary_f32_dev": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
+    # (stream|device, method, orders, n_orders, max_order, beta, n_beta, omega_ref, two_pi_c, atol, rtol, lambda1,
+    #  axis2, n2, axis3, n3, first, n, out, valid)
+    "psa_dbeta_grid_f64_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int] + [C.c_double] * 5
+                               + [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "psa_dbeta_grid_f32_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int] + [C.c_double] * 5
+                               + [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "psa_dbeta_grid_f64": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int] + [C.c_double] * 5
+                           + [_P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    # (stream|device, orders, n_orders, beta, n_beta, omega_d, axis1, n1, axis2, n2, first, n, out1, out2)
+    "psa_dbeta_pairs_f64_dev": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_double, _P, C.c_int64, _P, C.c_int64,
+                                          C.c_int64, C.c_int64, _P, _P]),
+    "psa_dbeta_pairs_f32_dev": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_double, _P, C.c_int64, _P, C.c_int64,
+                                          C.c_int64, C.c_int64, _P, _P]),
+    "psa_dbeta_pairs_f64": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_double, _P, C.c_int64, _P, C.c_int64,
+                                      C.c_int64, C.c_int64, _P, _P]),
 }
+DBETA_SYMMETRIC_EVEN, DBETA_GENERAL_TAYLOR = 0, 1
+DBETA_MAX_ORDER = 8
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 
@@ -234,27 +256,106 @@ def yaman_rhs_host(z, a, gamma, alpha, dbeta, *, terms: bool = False, device: in
 
 
 def gain_summary_host(p_metric, first_bad_step, p0_sig: float, *, gain_db: bool = True, device: int = 0):
-    """Per-point gain (NaN on failure) + (argmax, max, #finite) over the sweep, reduced on the GPU."""
-    p = np.ascontiguousarray(np.asarray(p_metric), dtype=np.float64)
+    """Per-point gain (NaN on failure) + (argmax, max, #finite) over the sweep, reduced on the GPU.
+    A float32 ``p_metric`` (a float32 sweep) goes through ``psa_gain_summary_f32`` and returns float32 gains."""
+    p = np.asarray(p_metric)
+    f32 = p.dtype == np.float32
+    p = np.ascontiguousarray(p, dtype=np.float32 if f32 else np.float64)
     bad = None if first_bad_step is None else np.ascontiguousarray(np.asarray(first_bad_step), dtype=np.int64)
     N = p.shape[0]
-    gain = np.empty(N, dtype=np.float64)
+    gain = np.empty(N, dtype=p.dtype)
     bi = C.c_int64(-1)
     bg = C.c_double(float("nan"))
     nf = C.c_int64(0)
-    _check(lib().psa_gain_summary_f64(int(device), N, _ptr(p), _ptr(bad), float(p0_sig), int(bool(gain_db)),
-                                      _ptr(gain), C.cast(C.byref(bi), _P), C.cast(C.byref(bg), _P),
-                                      C.cast(C.byref(nf), _P)))
+    fn = lib().psa_gain_summary_f32 if f32 else lib().psa_gain_summary_f64
+    _check(fn(int(device), N, _ptr(p), _ptr(bad), float(p0_sig), int(bool(gain_db)), _ptr(gain),
+              C.cast(C.byref(bi), _P), C.cast(C.byref(bg), _P), C.cast(C.byref(nf), _P)))
     return gain, int(bi.value), float(bg.value), int(nf.value)
 
 
 def gain_summary_device(*, stream: int, n_points: int, d_p_metric: int, d_first_bad: int, p0_sig: float, gain_db: bool,
-                        d_gain: int, d_best_index: int, d_best_gain: int, d_n_finite: int, d_workspace: int) -> None:
-    """Asynchronous gain reduction on device pointers (ints) -- see psa_gain_summary_f64_dev."""
-    _check(lib().psa_gain_summary_f64_dev(stream or None, int(n_points), d_p_metric or None, d_first_bad or None,
-                                          float(p0_sig), int(bool(gain_db)), d_gain or None, d_best_index or None,
-                                          d_best_gain or None, d_n_finite or None, d_workspace or None))
+                        d_gain: int, d_best_index: int, d_best_gain: int, d_n_finite: int, d_workspace: int,
+                        dtype=np.float64) -> None:
+    """Asynchronous gain reduction on device pointers (ints) -- see psa_gain_summary_f64_dev / _f32_dev."""
+    fn = lib().psa_gain_summary_f64_dev if np.dtype(dtype) == np.float64 else lib().psa_gain_summary_f32_dev
+    _check(fn(stream or None, int(n_points), d_p_metric or None, d_first_bad or None, float(p0_sig),
+              int(bool(gain_db)), d_gain or None, d_best_index or None, d_best_gain or None, d_n_finite or None,
+              d_workspace or None))
 
 
 def gain_summary_workspace_bytes(n_points: int) -> int:
     return int(lib().psa_gain_summary_workspace_bytes(int(n_points)))
+
+
+# ---- device-side dbeta producer (psa_dbeta_grid_* / psa_dbeta_pairs_*) -------------------------------------------
+def dbeta_model(disp, pm_cfg=None, *, even_orders=None) -> dict:
+    """The C-ABI's description of (DispersionParams, PhaseMatchingConfig): method, even orders / max order, beta_0..beta_8,
+    omega_ref, tolerances.  ``pm_cfg=None`` + ``even_orders`` describes the symmetric closed form alone (six-wave grid).
+    Raises ValueError for what the device producer does not cover (PROVIDED, orders above 8)."""
+    from .phase_matching import PhaseMatchingMethod
+    if disp is None:
+        raise ValueError("disp must be provided unless method == 'provided'")
+    top = DBETA_MAX_ORDER
+    if disp.extra is not None and any(int(k) > top and v != 0.0 for k, v in disp.extra.items()):
+        raise ValueError(f"the device dbeta producer covers dispersion orders up to {top}")
+    beta = np.array([disp.get_beta_n(n) for n in range(top + 1)], dtype=np.float64)
+    if pm_cfg is None:
+        method, orders, max_order, atol, rtol = DBETA_SYMMETRIC_EVEN, tuple(even_orders or (2, 4)), 0, 0.0, 1e-12
+    elif pm_cfg.method == PhaseMatchingMethod.SYMMETRIC_EVEN:
+        method, orders, max_order, atol, rtol = DBETA_SYMMETRIC_EVEN, tuple(pm_cfg.even_orders), 0, pm_cfg.atol, pm_cfg.rtol
+    elif pm_cfg.method == PhaseMatchingMethod.GENERAL_TAYLOR:
+        method, orders, max_order, atol, rtol = DBETA_GENERAL_TAYLOR, (), int(pm_cfg.max_order), pm_cfg.atol, pm_cfg.rtol
+    else:
+        raise ValueError("a PROVIDED dbeta is an input, not something to generate")
+    if method == DBETA_SYMMETRIC_EVEN and (not 1 <= len(orders) <= 4 or any(n > top for n in orders)):
+        raise ValueError(f"the device dbeta producer takes 1..4 even orders up to {top}")
+    if method == DBETA_GENERAL_TAYLOR and max_order > top:
+        raise ValueError(f"the device dbeta producer covers max_order up to {top}")
+    from . import constants
+    return dict(method=method, orders=np.asarray(orders, dtype=np.int32), max_order=max_order, beta=beta,
+                omega_ref=float(disp.omega_ref), two_pi_c=2.0 * np.pi * constants.c, atol=float(atol), rtol=float(rtol))
+
+
+def _model_head(m: dict):
+    return (int(m["method"]), _ptr(m["orders"]) if m["orders"].size else None, int(m["orders"].size), int(m["max_order"]),
+            _ptr(m["beta"]), int(m["beta"].size), m["omega_ref"], m["two_pi_c"], m["atol"], m["rtol"])
+
+
+def dbeta_grid_host(model: dict, lambda1_m: float, lambda2_axis, lambda3_axis, *, first: int = 0,
+                    n_points: Optional[int] = None, device: int = 0):
+    """dbeta (and validity) of points [first, first + n_points) of the flattened lambda2 x lambda3 grid, on the GPU."""
+    ax2 = np.ascontiguousarray(np.atleast_1d(lambda2_axis), dtype=np.float64)
+    ax3 = np.ascontiguousarray(np.atleast_1d(lambda3_axis), dtype=np.float64)
+    n = ax2.size * ax3.size - int(first) if n_points is None else int(n_points)
+    out = np.empty(n, dtype=np.float64)
+    valid = np.empty(n, dtype=np.uint8)
+    _check(lib().psa_dbeta_grid_f64(int(device), *_model_head(model), float(lambda1_m), _ptr(ax2), ax2.size, _ptr(ax3),
+                                    ax3.size, int(first), n, _ptr(out), _ptr(valid)))
+    return out, valid.astype(bool)
+
+
+def dbeta_grid_device(model: dict, lambda1_m: float, *, stream: int, d_lambda2_axis: int, n2: int, d_lambda3_axis: int,
+                      n3: int, first: int, n_points: int, d_dbeta: int, d_valid: int = 0, dtype=np.float64) -> None:
+    fn = lib().psa_dbeta_grid_f64_dev if np.dtype(dtype) == np.float64 else lib().psa_dbeta_grid_f32_dev
+    _check(fn(stream or None, *_model_head(model), float(lambda1_m), d_lambda2_axis or None, int(n2),
+              d_lambda3_axis or None, int(n3), int(first), int(n_points), d_dbeta or None, d_valid or None))
+
+
+def dbeta_pairs_host(model: dict, omega_d: float, Omega1_axis, Omega2_axis, *, first: int = 0,
+                     n_points: Optional[int] = None, device: int = 0):
+    ax1 = np.ascontiguousarray(np.atleast_1d(Omega1_axis), dtype=np.float64)
+    ax2 = np.ascontiguousarray(np.atleast_1d(Omega2_axis), dtype=np.float64)
+    n = ax1.size * ax2.size - int(first) if n_points is None else int(n_points)
+    o1, o2 = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.float64)
+    _check(lib().psa_dbeta_pairs_f64(int(device), _ptr(model["orders"]), int(model["orders"].size), _ptr(model["beta"]),
+                                     int(model["beta"].size), float(omega_d), _ptr(ax1), ax1.size, _ptr(ax2), ax2.size,
+                                     int(first), n, _ptr(o1), _ptr(o2)))
+    return o1, o2
+
+
+def dbeta_pairs_device(model: dict, omega_d: float, *, stream: int, d_Omega1_axis: int, n1: int, d_Omega2_axis: int,
+                       n2: int, first: int, n_points: int, d_dbeta1: int, d_dbeta2: int, dtype=np.float64) -> None:
+    fn = lib().psa_dbeta_pairs_f64_dev if np.dtype(dtype) == np.float64 else lib().psa_dbeta_pairs_f32_dev
+    _check(fn(stream or None, _ptr(model["orders"]), int(model["orders"].size), _ptr(model["beta"]),
+              int(model["beta"].size), float(omega_d), d_Omega1_axis or None, int(n1), d_Omega2_axis or None, int(n2),
+              int(first), int(n_points), d_dbeta1 or None, d_dbeta2 or None))

@@ -24,16 +24,18 @@ __global__ void __launch_bounds__(256) soa_to_aos_kernel(const T *__restrict__ s
 // traj device layout [rows][nw][n] of (re, im) pairs -> NumPy layout [n][rows][nw] of pairs: a 2-D transpose of
 // 16-B (f64) / 8-B (f32) elements.  A 32-point x 32-(row,wave) tile goes through LDS so that both the global reads
 // (n fastest) and the global writes ((row, wave) fastest) are contiguous runs; +1 column: conflict-free.
+// The host-buffer API transposes a CHUNK of points at a time into a bounded staging buffer: `soa` points at the chunk's
+// first point inside the full [rows*nw][ld] device buffer, `aos` receives [n][rows*nw].
 template <typename P2>
 __global__ void __launch_bounds__(256) traj_to_aos_kernel(const P2 *__restrict__ soa, P2 *__restrict__ aos,
-                                                          long long n, long long rw_total) {
+                                                          long long n, long long ld, long long rw_total) {
     __shared__ P2 tile[32][33];
     const long long p0 = (long long)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 rows of 32 threads
     for (long long rw0 = (long long)blockIdx.y * 32; rw0 < rw_total; rw0 += (long long)gridDim.y * 32) {
         for (int r = ty; r < 32; r += 8) {
             const long long rw = rw0 + r;
-            if (rw < rw_total && p0 + tx < n) tile[r][tx] = soa[rw * n + p0 + tx];
+            if (rw < rw_total && p0 + tx < n) tile[r][tx] = soa[rw * ld + p0 + tx];
         }
         __syncthreads();
         for (int p = ty; p < 32; p += 8) {
@@ -57,14 +59,14 @@ static hipError_t launch_s2a(hipStream_t s, const T *soa, T *aos, long long n, i
     return hipGetLastError();
 }
 template <typename T>
-static hipError_t launch_t2a(hipStream_t s, const T *soa, T *aos, long long n, long long rows, int nc) {
+static hipError_t launch_t2a(hipStream_t s, const T *soa, T *aos, long long n, long long ld, long long rows, int nc) {
     if (n == 0 || rows == 0) return hipSuccess;
     typedef T P2 __attribute__((ext_vector_type(2)));
     const long long rw_total = rows * (nc / 2);
     const long long chunks = (rw_total + 31) / 32;
     const unsigned gy = (unsigned)(chunks < 64 ? chunks : 64);
     hipLaunchKernelGGL((traj_to_aos_kernel<P2>), dim3((unsigned)((n + 31) / 32), gy), dim3(256), 0, s,
-                       reinterpret_cast<const P2 *>(soa), reinterpret_cast<P2 *>(aos), n, rw_total);
+                       reinterpret_cast<const P2 *>(soa), reinterpret_cast<P2 *>(aos), n, ld, rw_total);
     return hipGetLastError();
 }
 
@@ -72,8 +74,8 @@ hipError_t launch_aos_to_soa_f64(hipStream_t s, const double *a, double *b, long
 hipError_t launch_soa_to_aos_f64(hipStream_t s, const double *a, double *b, long long n, int nc) { return launch_s2a(s, a, b, n, nc); }
 hipError_t launch_aos_to_soa_f32(hipStream_t s, const float *a, float *b, long long n, int nc) { return launch_a2s(s, a, b, n, nc); }
 hipError_t launch_soa_to_aos_f32(hipStream_t s, const float *a, float *b, long long n, int nc) { return launch_s2a(s, a, b, n, nc); }
-hipError_t launch_traj_to_aos_f64(hipStream_t s, const double *a, double *b, long long n, long long r, int nc) { return launch_t2a(s, a, b, n, r, nc); }
-hipError_t launch_traj_to_aos_f32(hipStream_t s, const float *a, float *b, long long n, long long r, int nc) { return launch_t2a(s, a, b, n, r, nc); }
+hipError_t launch_traj_to_aos_f64(hipStream_t s, const double *a, double *b, long long n, long long ld, long long r, int nc) { return launch_t2a(s, a, b, n, ld, r, nc); }
+hipError_t launch_traj_to_aos_f32(hipStream_t s, const float *a, float *b, long long n, long long ld, long long r, int nc) { return launch_t2a(s, a, b, n, ld, r, nc); }
 
 // ---- one RHS evaluation per point (yaman_model.py:10-52), terms kept separate ---------------------
 // Written term by term in the reference's own grouping (linear + kerr) + fwm so the three partial
@@ -167,19 +169,21 @@ __device__ __forceinline__ Best block_reduce(Best v, Best *sm) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) gain_pass1(long long n, const double *__restrict__ p_metric,
+// T = the sweep's arithmetic type: p_metric and the per-point gain are T, the ratio and log10 are formed in float64
+template <typename T>
+__global__ void __launch_bounds__(256) gain_pass1(long long n, const T *__restrict__ p_metric,
                                                   const long long *__restrict__ first_bad, double p0, int gain_db,
-                                                  double *__restrict__ gain_out, Best *__restrict__ partial) {
+                                                  T *__restrict__ gain_out, Best *__restrict__ partial) {
     __shared__ Best sm[4];
     Best acc{0.0, -1, 0};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const double p = p_metric[i];
+        const double p = (double)p_metric[i];
         double g = p / p0;
         // scan_mismtach.py:377-384: non-finite P3, non-finite or <= 0 gain -> NaN; :391 any exception -> NaN
         const bool ok = (p - p == 0.0) && (g - g == 0.0) && (g > 0.0) && (first_bad == nullptr || first_bad[i] < 0);
         if (ok && gain_db) g = 10.0 * log10(g);
         g = ok ? g : __builtin_nan("");
-        if (gain_out) gain_out[i] = g;
+        if (gain_out) gain_out[i] = (T)g;
         if (ok) acc = best_merge(acc, Best{g, i, 1});
     }
     acc = block_reduce(acc, sm);
@@ -207,15 +211,26 @@ static int gain_blocks(long long n) {
 }
 long long gain_summary_workspace_bytes(long long n) { return (long long)gain_blocks(n) * (long long)sizeof(Best); }
 
-hipError_t launch_gain_summary_f64(hipStream_t s, long long n, const double *p_metric, const long long *first_bad,
-                                   double p0_sig, int gain_db, double *gain_out, long long *best_index,
-                                   double *best_gain, long long *n_finite, void *workspace) {
+template <typename T>
+static hipError_t launch_gain_summary_t(hipStream_t s, long long n, const T *p_metric, const long long *first_bad,
+                                        double p0_sig, int gain_db, T *gain_out, long long *best_index,
+                                        double *best_gain, long long *n_finite, void *workspace) {
     const int nb = gain_blocks(n);
-    hipLaunchKernelGGL(gain_pass1, dim3(nb), dim3(256), 0, s, n, p_metric, first_bad, p0_sig, gain_db, gain_out,
+    hipLaunchKernelGGL(gain_pass1<T>, dim3(nb), dim3(256), 0, s, n, p_metric, first_bad, p0_sig, gain_db, gain_out,
                        (Best *)workspace);
     hipLaunchKernelGGL(gain_pass2, dim3(1), dim3(256), 0, s, nb, (const Best *)workspace, best_index, best_gain,
                        n_finite);
     return hipGetLastError();
+}
+hipError_t launch_gain_summary_f64(hipStream_t s, long long n, const double *p_metric, const long long *first_bad,
+                                   double p0_sig, int gain_db, double *gain_out, long long *best_index,
+                                   double *best_gain, long long *n_finite, void *workspace) {
+    return launch_gain_summary_t<double>(s, n, p_metric, first_bad, p0_sig, gain_db, gain_out, best_index, best_gain, n_finite, workspace);
+}
+hipError_t launch_gain_summary_f32(hipStream_t s, long long n, const float *p_metric, const long long *first_bad,
+                                   double p0_sig, int gain_db, float *gain_out, long long *best_index,
+                                   double *best_gain, long long *n_finite, void *workspace) {
+    return launch_gain_summary_t<float>(s, n, p_metric, first_bad, p0_sig, gain_db, gain_out, best_index, best_gain, n_finite, workspace);
 }
 
 }  // namespace psa

@@ -41,6 +41,8 @@ int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max
                     const void *a_end, const void *p_end, const void *p_max, const void *first_bad) {
     if (n_waves != 4 && n_waves != 6) return fail(PSA_E_NWAVES, "n_waves must be 4 or 6, got %d", n_waves);
     if (n_points < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0, got %lld", (long long)n_points);
+    // one 64-thread workgroup per wave at the finest launch shape; the grid's x extent is a 32-bit count
+    if (n_points > 64LL * 2147483647LL) return fail(PSA_E_TOO_LARGE, "n_points %lld exceeds the launch grid limit", (long long)n_points);
     if (n_steps <= 0 || n_steps > 2147483647LL)
         return fail(PSA_E_NSTEPS, "n_steps must be in [1, 2^31), got %lld", (long long)n_steps);
     if (!(z_max > 0.0) || !std::isfinite(z_max)) return fail(PSA_E_ZMAX, "z_max must be positive");
@@ -88,11 +90,12 @@ template <typename T> struct Launch;
 template <> struct Launch<double> {
     static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
                             const psa::SweepArgs<double> &a) {
-        return psa::launch_sweep_f64(s, nw, chk, lds, blk, (flags & PSA_OPT_LOSSLESS) != 0, a);
+        const int split = (flags & PSA_OPT_SPLIT_POINT) ? 1 : ((flags & PSA_OPT_ONE_LANE) ? 0 : -1);
+        return psa::launch_sweep_f64(s, nw, chk, lds, blk, (flags & PSA_OPT_LOSSLESS) != 0, split, a);
     }
     static hipError_t a2s(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_aos_to_soa_f64(s, a, b, n, nc); }
     static hipError_t s2a(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_soa_to_aos_f64(s, a, b, n, nc); }
-    static hipError_t t2a(hipStream_t s, const double *a, double *b, long long n, long long r, int nc) { return psa::launch_traj_to_aos_f64(s, a, b, n, r, nc); }
+    static hipError_t t2a(hipStream_t s, const double *a, double *b, long long n, long long ld, long long r, int nc) { return psa::launch_traj_to_aos_f64(s, a, b, n, ld, r, nc); }
 };
 template <> struct Launch<float> {
     static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
@@ -104,7 +107,7 @@ template <> struct Launch<float> {
     }
     static hipError_t a2s(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_aos_to_soa_f32(s, a, b, n, nc); }
     static hipError_t s2a(hipStream_t s, const float *a, float *b, long long n, int nc) { return psa::launch_soa_to_aos_f32(s, a, b, n, nc); }
-    static hipError_t t2a(hipStream_t s, const float *a, float *b, long long n, long long r, int nc) { return psa::launch_traj_to_aos_f32(s, a, b, n, r, nc); }
+    static hipError_t t2a(hipStream_t s, const float *a, float *b, long long n, long long ld, long long r, int nc) { return psa::launch_traj_to_aos_f32(s, a, b, n, ld, r, nc); }
 };
 
 template <typename T>
@@ -131,6 +134,33 @@ struct DevBuf {
     template <typename U> U *as() { return (U *)p; }
 };
 
+// Makes `device` current for the scope of a host-buffer entry point and puts the caller's device back afterwards
+// (a host-API call must not leave a side effect on a thread that also drives torch or another HIP library).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev == device) return hipSuccess;
+        e = hipSetDevice(device);
+        switched = (e == hipSuccess);
+        return e;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
+int check_device(int device, const char *what) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PSA_E_DEVICE, "no HIP device visible: %s has no CPU fallback", what);
+    if (device < 0 || device >= ndev) return fail(PSA_E_DEVICE, "device %d out of range [0, %d)", device, ndev);
+    return PSA_OK;
+}
+
+// staging for the trajectory transpose of the host-buffer API: two buffers of at most this many bytes each
+constexpr size_t TRAJ_STAGE_BYTES = 256u << 20;
+
 template <typename T>
 int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max, int32_t save_every,
                const T *dbeta, const T *dbeta2, const T *gamma, const T *alpha, const T *a0, uint32_t flags,
@@ -140,10 +170,8 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     if (rc != PSA_OK) return rc;
     if (elapsed_ms) *elapsed_ms = 0.0;
     if (n_points == 0) return PSA_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(PSA_E_DEVICE, "no HIP device visible: the RK4 sweep has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(PSA_E_DEVICE, "device %d out of range [0, %d)", device, ndev);
+    rc = check_device(device, "the RK4 sweep");
+    if (rc != PSA_OK) return rc;
 
     const int nc = 2 * n_waves;
     const size_t N = (size_t)n_points;
@@ -160,12 +188,34 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     const size_t n_alpha = (flags & PSA_BCAST_ALPHA) ? 1 : N;
     const size_t n_a0 = (flags & PSA_BCAST_A0) ? 1 : N;
 
-    DevBuf b_dbeta, b_dbeta2, b_gamma, b_alpha, b_a0_aos, b_a0_soa, b_aend_soa, b_aend_aos, b_pend, b_pmax, b_bad,
-        b_traj_soa, b_traj_aos;
-    hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // trajectory rows leave the device in chunks of points: [rows][nw][N] -> chunk [pts][rows][nw] in a bounded staging
+    // buffer (two of them, so a chunk's device-to-host copy overlaps the next chunk's transpose)
+    const size_t point_bytes = (size_t)n_saved * nc * sizeof(T);          // one point's whole trajectory
+    size_t chunk_pts = 0;
+    if (traj && N > 1) {
+        chunk_pts = (TRAJ_STAGE_BYTES / point_bytes) / 32 * 32;            // whole 32-point transpose tiles
+        if (chunk_pts < 32) chunk_pts = 32;                                // (very long single runs: one tile per chunk)
+        if (chunk_pts > N) chunk_pts = N;
+    }
 
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope scope;
+    DevBuf b_dbeta, b_dbeta2, b_gamma, b_alpha, b_a0_aos, b_a0_soa, b_aend_soa, b_aend_aos, b_pend, b_pmax, b_bad,
+        b_traj_soa, b_stage[2];
+    hipStream_t st = nullptr, st_copy[2] = {nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_kernel = nullptr;
+
+    HIP_TRY(scope.enter(device));
+    if (traj) {   // say "too large" before hipMalloc says "out of memory"
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const long double need = (long double)traj_elems * sizeof(T) + 2.0L * (long double)chunk_pts * point_bytes
+                                 + (long double)N * (3 * nc + 4) * sizeof(T);
+        if (need > (long double)free_b) {
+            rc = fail(PSA_E_TOO_LARGE, "trajectory of %.3g GB does not fit the %.3g GB free on device %d",
+                      (double)(need / 1e9L), (double)free_b / 1e9, device);
+            goto done;
+        }
+    }
     HIP_TRY(hipStreamCreate(&st));
     HIP_TRY(b_dbeta.alloc(N * sizeof(T)));
     if (dbeta2) HIP_TRY(b_dbeta2.alloc(N * sizeof(T)));
@@ -178,10 +228,7 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     HIP_TRY(b_pend.alloc(N * sizeof(T)));
     HIP_TRY(b_pmax.alloc(N * sizeof(T)));
     HIP_TRY(b_bad.alloc(N * sizeof(int64_t)));
-    if (traj) {
-        HIP_TRY(b_traj_soa.alloc(traj_elems * sizeof(T)));
-        if (N > 1) HIP_TRY(b_traj_aos.alloc(traj_elems * sizeof(T)));
-    }
+    if (traj) HIP_TRY(b_traj_soa.alloc(traj_elems * sizeof(T)));
     HIP_TRY(hipMemcpyAsync(b_dbeta.p, dbeta, N * sizeof(T), hipMemcpyHostToDevice, st));
     if (dbeta2) HIP_TRY(hipMemcpyAsync(b_dbeta2.p, dbeta2, N * sizeof(T), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b_gamma.p, gamma, n_gamma * sizeof(T), hipMemcpyHostToDevice, st));
@@ -202,13 +249,27 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     HIP_TRY(hipMemcpyAsync(p_end, b_pend.p, N * sizeof(T), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(p_max, b_pmax.p, N * sizeof(T), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(first_bad, b_bad.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    if (traj) {
-        if (N > 1) {  // [rows][nc][N] -> [N][rows][nc]; for N == 1 the two layouts coincide
-            HIP_TRY(Launch<T>::t2a(st, b_traj_soa.as<T>(), b_traj_aos.as<T>(), (long long)N, (long long)n_saved, nc));
-            HIP_TRY(hipMemcpyAsync(traj, b_traj_aos.p, traj_elems * sizeof(T), hipMemcpyDeviceToHost, st));
-        } else {
-            HIP_TRY(hipMemcpyAsync(traj, b_traj_soa.p, traj_elems * sizeof(T), hipMemcpyDeviceToHost, st));
+    if (traj && N == 1) {   // [rows][nw][1] and [1][rows][nw] coincide
+        HIP_TRY(hipMemcpyAsync(traj, b_traj_soa.p, traj_elems * sizeof(T), hipMemcpyDeviceToHost, st));
+    } else if (traj) {
+        HIP_TRY(hipEventCreateWithFlags(&ev_kernel, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_kernel, st));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(b_stage[b].alloc(chunk_pts * point_bytes));
+            HIP_TRY(hipStreamCreate(&st_copy[b]));
+            HIP_TRY(hipStreamWaitEvent(st_copy[b], ev_kernel, 0));
         }
+        int b = 0;
+        for (size_t p0 = 0; p0 < N; p0 += chunk_pts, b ^= 1) {
+            const size_t pts = (N - p0 < chunk_pts) ? N - p0 : chunk_pts;
+            // stream order on st_copy[b] keeps the staging buffer busy until its previous copy has finished
+            HIP_TRY(Launch<T>::t2a(st_copy[b], b_traj_soa.as<T>() + 2 * p0, b_stage[b].as<T>(), (long long)pts,
+                                   (long long)N, (long long)n_saved, nc));
+            HIP_TRY(hipMemcpyAsync(traj + p0 * (size_t)n_saved * nc, b_stage[b].p, pts * point_bytes,
+                                   hipMemcpyDeviceToHost, st_copy[b]));
+        }
+        HIP_TRY(hipStreamSynchronize(st_copy[0]));
+        HIP_TRY(hipStreamSynchronize(st_copy[1]));
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (elapsed_ms) {
@@ -217,13 +278,138 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
         *elapsed_ms = (double)ms;
     }
 done:
+    for (int b = 0; b < 2; ++b) {
+        if (st_copy[b]) {
+            (void)hipStreamSynchronize(st_copy[b]);
+            (void)hipStreamDestroy(st_copy[b]);
+        }
+    }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_kernel) (void)hipEventDestroy(ev_kernel);
     if (st) {
         (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
     }
     return rc;
+}
+
+template <typename T> struct GainLaunch;
+template <> struct GainLaunch<double> { static constexpr auto fn = psa::launch_gain_summary_f64; };
+template <> struct GainLaunch<float> { static constexpr auto fn = psa::launch_gain_summary_f32; };
+
+template <typename T>
+int gain_summary_dev(void *stream, int64_t n, const T *d_p, const int64_t *d_bad, double p0_sig, int gain_db, T *d_gain,
+                     int64_t *d_best_i, double *d_best_g, int64_t *d_nfin, void *d_ws) {
+    if (n < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0");
+    if (!d_best_i || !d_best_g || !d_nfin || !d_ws || (n > 0 && !d_p))
+        return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    hipError_t e = GainLaunch<T>::fn((hipStream_t)stream, n, d_p, (const long long *)d_bad, p0_sig, gain_db, d_gain,
+                                     (long long *)d_best_i, d_best_g, (long long *)d_nfin, d_ws);
+    if (e != hipSuccess) return hip_fail(e, "gain_summary launch");
+    return PSA_OK;
+}
+
+template <typename T>
+int gain_summary_host(int device, int64_t n, const T *p_metric, const int64_t *first_bad, double p0_sig, int gain_db,
+                      T *gain_out, int64_t *best_index, double *best_gain, int64_t *n_finite) {
+    if (n < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0");
+    if (!best_index || !best_gain || !n_finite || (n > 0 && !p_metric))
+        return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    int rc = check_device(device, "the gain summary");
+    if (rc != PSA_OK) return rc;
+    const size_t N = (size_t)n;
+    DeviceScope scope;
+    DevBuf bp, bb, bg, bi, bbg, bn, bw;
+    HIP_TRY(scope.enter(device));
+    HIP_TRY(bp.alloc(N * sizeof(T)));
+    if (first_bad) HIP_TRY(bb.alloc(N * 8));
+    if (gain_out) HIP_TRY(bg.alloc(N * sizeof(T)));
+    HIP_TRY(bi.alloc(8)); HIP_TRY(bbg.alloc(8)); HIP_TRY(bn.alloc(8));
+    HIP_TRY(bw.alloc((size_t)psa::gain_summary_workspace_bytes(n)));
+    if (N) HIP_TRY(hipMemcpy(bp.p, p_metric, N * sizeof(T), hipMemcpyHostToDevice));
+    if (first_bad && N) HIP_TRY(hipMemcpy(bb.p, first_bad, N * 8, hipMemcpyHostToDevice));
+    rc = gain_summary_dev<T>(nullptr, n, bp.as<T>(), first_bad ? bb.as<int64_t>() : nullptr, p0_sig, gain_db,
+                             gain_out ? bg.as<T>() : nullptr, bi.as<int64_t>(), bbg.as<double>(), bn.as<int64_t>(), bw.p);
+    if (rc != PSA_OK) goto done;
+    if (gain_out && N) HIP_TRY(hipMemcpy(gain_out, bg.p, N * sizeof(T), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(best_index, bi.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(best_gain, bbg.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_finite, bn.p, 8, hipMemcpyDeviceToHost));
+done:
+    return rc;
+}
+
+// dbeta producer: argument checks + the model struct shared by both kernels
+int make_dbeta_model(psa::DbetaModel &m, int method, const int32_t *orders, int n_orders, int max_order,
+                     const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol) {
+    if (method != PSA_DBETA_SYMMETRIC_EVEN && method != PSA_DBETA_GENERAL_TAYLOR)
+        return fail(PSA_E_DBETA_MODEL, "method must be PSA_DBETA_SYMMETRIC_EVEN or PSA_DBETA_GENERAL_TAYLOR");
+    if (!beta || n_beta < 1 || n_beta > psa::DBETA_MAX_ORDER + 1)
+        return fail(PSA_E_DBETA_MODEL, "beta must hold 1..%d coefficients", psa::DBETA_MAX_ORDER + 1);
+    for (int n = 0; n <= psa::DBETA_MAX_ORDER; ++n) m.beta[n] = n < n_beta ? beta[n] : 0.0;
+    m.omega_ref = omega_ref; m.two_pi_c = two_pi_c; m.atol = atol; m.rtol = rtol;
+    m.method = method; m.n_orders = 0; m.max_order = 0;
+    for (int k = 0; k < 4; ++k) m.orders[k] = 0;
+    if (method == PSA_DBETA_SYMMETRIC_EVEN) {
+        if (!orders || n_orders < 1 || n_orders > 4) return fail(PSA_E_DBETA_MODEL, "1..4 even orders expected");
+        for (int k = 0; k < n_orders; ++k) {
+            if (orders[k] < 2 || orders[k] % 2 || orders[k] > psa::DBETA_MAX_ORDER)
+                return fail(PSA_E_DBETA_MODEL, "even_orders must be even ints in [2, %d], got %d", psa::DBETA_MAX_ORDER, orders[k]);
+            m.orders[k] = orders[k];
+        }
+        m.n_orders = n_orders;
+    } else {
+        if (max_order < 0 || max_order > psa::DBETA_MAX_ORDER)
+            return fail(PSA_E_DBETA_MODEL, "max_order must be in [0, %d]", psa::DBETA_MAX_ORDER);
+        m.max_order = max_order;
+    }
+    return PSA_OK;
+}
+
+template <typename T> struct DbetaLaunch;
+template <> struct DbetaLaunch<double> {
+    static constexpr auto grid = psa::launch_dbeta_grid_f64;
+    static constexpr auto pairs = psa::launch_dbeta_pairs_f64;
+};
+template <> struct DbetaLaunch<float> {
+    static constexpr auto grid = psa::launch_dbeta_grid_f32;
+    static constexpr auto pairs = psa::launch_dbeta_pairs_f32;
+};
+
+template <typename T>
+int dbeta_grid_dev(void *stream, int method, const int32_t *orders, int n_orders, int max_order, const double *beta,
+                   int n_beta, double omega_ref, double two_pi_c, double atol, double rtol, double lambda1_m,
+                   const double *d_ax2, int64_t n2, const double *d_ax3, int64_t n3, int64_t first, int64_t n, T *d_out,
+                   uint8_t *d_valid) {
+    psa::DbetaModel m;
+    int rc = make_dbeta_model(m, method, orders, n_orders, max_order, beta, n_beta, omega_ref, two_pi_c, atol, rtol);
+    if (rc != PSA_OK) return rc;
+    if (n < 0 || n2 <= 0 || n3 <= 0 || first < 0) return fail(PSA_E_NPOINTS, "n_points / axes / first_index out of range");
+    if ((long double)first + (long double)n > (long double)n2 * (long double)n3)
+        return fail(PSA_E_NPOINTS, "[first_index, first_index + n_points) leaves the %lld x %lld grid", (long long)n2, (long long)n3);
+    if (n == 0) return PSA_OK;
+    if (!d_ax2 || !d_ax3 || !d_out) return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    hipError_t e = DbetaLaunch<T>::grid((hipStream_t)stream, m, lambda1_m, d_ax2, n2, d_ax3, n3, first, n, d_out, d_valid);
+    if (e != hipSuccess) return hip_fail(e, "dbeta_grid launch");
+    return PSA_OK;
+}
+
+template <typename T>
+int dbeta_pairs_dev(void *stream, const int32_t *orders, int n_orders, const double *beta, int n_beta, double omega_d,
+                    const double *d_ax1, int64_t n1, const double *d_ax2, int64_t n2, int64_t first, int64_t n,
+                    T *d_out1, T *d_out2) {
+    psa::DbetaModel m;
+    int rc = make_dbeta_model(m, PSA_DBETA_SYMMETRIC_EVEN, orders, n_orders, 0, beta, n_beta, 1.0, 0.0, 0.0, 0.0);
+    if (rc != PSA_OK) return rc;
+    if (n < 0 || n1 <= 0 || n2 <= 0 || first < 0) return fail(PSA_E_NPOINTS, "n_points / axes / first_index out of range");
+    if ((long double)first + (long double)n > (long double)n1 * (long double)n2)
+        return fail(PSA_E_NPOINTS, "[first_index, first_index + n_points) leaves the %lld x %lld grid", (long long)n1, (long long)n2);
+    if (n == 0) return PSA_OK;
+    if (!d_ax1 || !d_ax2 || !d_out1 || !d_out2) return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    hipError_t e = DbetaLaunch<T>::pairs((hipStream_t)stream, m, omega_d, d_ax1, n1, d_ax2, n2, first, n, d_out1, d_out2);
+    if (e != hipSuccess) return hip_fail(e, "dbeta_pairs launch");
+    return PSA_OK;
 }
 
 }  // namespace
@@ -277,14 +463,12 @@ int psa_yaman_rhs_f64(int device, int64_t n, const double *z, const double *a, c
     if (n < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0");
     if (n == 0) return PSA_OK;
     if (!z || !a || !gamma || !alpha || !dbeta || !out) return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(PSA_E_DEVICE, "no HIP device visible: the RHS kernel has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(PSA_E_DEVICE, "device %d out of range [0, %d)", device, ndev);
-    int rc = PSA_OK;
+    int rc = check_device(device, "the RHS kernel");
+    if (rc != PSA_OK) return rc;
     const size_t N = (size_t)n;
+    DeviceScope scope;
     DevBuf bz, ba, bg, bal, bd, bo, bl, bk, bf;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(scope.enter(device));
     HIP_TRY(bz.alloc(N * 8)); HIP_TRY(ba.alloc(N * 64)); HIP_TRY(bg.alloc(N * 8)); HIP_TRY(bal.alloc(N * 8));
     HIP_TRY(bd.alloc(N * 8)); HIP_TRY(bo.alloc(N * 64));
     if (out_lin) HIP_TRY(bl.alloc(N * 64));
@@ -311,43 +495,98 @@ int64_t psa_gain_summary_workspace_bytes(int64_t n) { return psa::gain_summary_w
 int psa_gain_summary_f64_dev(void *stream, int64_t n, const double *d_p, const int64_t *d_bad, double p0_sig,
                              int gain_db, double *d_gain, int64_t *d_best_i, double *d_best_g, int64_t *d_nfin,
                              void *d_ws) {
-    if (n < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0");
-    if (!d_best_i || !d_best_g || !d_nfin || !d_ws || (n > 0 && !d_p))
-        return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
-    hipError_t e = psa::launch_gain_summary_f64((hipStream_t)stream, n, d_p, (const long long *)d_bad, p0_sig, gain_db,
-                                                d_gain, (long long *)d_best_i, d_best_g, (long long *)d_nfin, d_ws);
-    if (e != hipSuccess) return hip_fail(e, "gain_summary launch");
-    return PSA_OK;
+    return gain_summary_dev<double>(stream, n, d_p, d_bad, p0_sig, gain_db, d_gain, d_best_i, d_best_g, d_nfin, d_ws);
 }
-
+int psa_gain_summary_f32_dev(void *stream, int64_t n, const float *d_p, const int64_t *d_bad, double p0_sig,
+                             int gain_db, float *d_gain, int64_t *d_best_i, double *d_best_g, int64_t *d_nfin,
+                             void *d_ws) {
+    return gain_summary_dev<float>(stream, n, d_p, d_bad, p0_sig, gain_db, d_gain, d_best_i, d_best_g, d_nfin, d_ws);
+}
 int psa_gain_summary_f64(int device, int64_t n, const double *p_metric, const int64_t *first_bad, double p0_sig,
                          int gain_db, double *gain_out, int64_t *best_index, double *best_gain, int64_t *n_finite) {
-    if (n < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0");
-    if (!best_index || !best_gain || !n_finite || (n > 0 && !p_metric))
-        return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(PSA_E_DEVICE, "no HIP device visible: the gain summary has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(PSA_E_DEVICE, "device %d out of range [0, %d)", device, ndev);
-    int rc = PSA_OK;
-    const size_t N = (size_t)n;
-    DevBuf bp, bb, bg, bi, bbg, bn, bw;
-    HIP_TRY(hipSetDevice(device));
-    HIP_TRY(bp.alloc(N * 8));
-    if (first_bad) HIP_TRY(bb.alloc(N * 8));
-    if (gain_out) HIP_TRY(bg.alloc(N * 8));
-    HIP_TRY(bi.alloc(8)); HIP_TRY(bbg.alloc(8)); HIP_TRY(bn.alloc(8));
-    HIP_TRY(bw.alloc((size_t)psa::gain_summary_workspace_bytes(n)));
-    if (N) HIP_TRY(hipMemcpy(bp.p, p_metric, N * 8, hipMemcpyHostToDevice));
-    if (first_bad && N) HIP_TRY(hipMemcpy(bb.p, first_bad, N * 8, hipMemcpyHostToDevice));
-    rc = psa_gain_summary_f64_dev(nullptr, n, bp.as<double>(), first_bad ? bb.as<int64_t>() : nullptr, p0_sig, gain_db,
-                                  gain_out ? bg.as<double>() : nullptr, bi.as<int64_t>(), bbg.as<double>(),
-                                  bn.as<int64_t>(), bw.p);
+    return gain_summary_host<double>(device, n, p_metric, first_bad, p0_sig, gain_db, gain_out, best_index, best_gain, n_finite);
+}
+int psa_gain_summary_f32(int device, int64_t n, const float *p_metric, const int64_t *first_bad, double p0_sig,
+                         int gain_db, float *gain_out, int64_t *best_index, double *best_gain, int64_t *n_finite) {
+    return gain_summary_host<float>(device, n, p_metric, first_bad, p0_sig, gain_db, gain_out, best_index, best_gain, n_finite);
+}
+
+/* ---- device-side dbeta producer ---------------------------------------------------------------------------- */
+int psa_dbeta_grid_f64_dev(void *stream, int method, const int32_t *orders, int n_orders, int max_order,
+                           const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol,
+                           double lambda1_m, const double *d_lambda2_axis, int64_t n2, const double *d_lambda3_axis,
+                           int64_t n3, int64_t first_index, int64_t n_points, double *d_dbeta, uint8_t *d_valid) {
+    return dbeta_grid_dev<double>(stream, method, orders, n_orders, max_order, beta, n_beta, omega_ref, two_pi_c, atol,
+                                  rtol, lambda1_m, d_lambda2_axis, n2, d_lambda3_axis, n3, first_index, n_points, d_dbeta,
+                                  d_valid);
+}
+int psa_dbeta_grid_f32_dev(void *stream, int method, const int32_t *orders, int n_orders, int max_order,
+                           const double *beta, int n_beta, double omega_ref, double two_pi_c, double atol, double rtol,
+                           double lambda1_m, const double *d_lambda2_axis, int64_t n2, const double *d_lambda3_axis,
+                           int64_t n3, int64_t first_index, int64_t n_points, float *d_dbeta, uint8_t *d_valid) {
+    return dbeta_grid_dev<float>(stream, method, orders, n_orders, max_order, beta, n_beta, omega_ref, two_pi_c, atol,
+                                 rtol, lambda1_m, d_lambda2_axis, n2, d_lambda3_axis, n3, first_index, n_points, d_dbeta,
+                                 d_valid);
+}
+int psa_dbeta_pairs_f64_dev(void *stream, const int32_t *orders, int n_orders, const double *beta, int n_beta,
+                            double omega_d, const double *d_Omega1_axis, int64_t n1, const double *d_Omega2_axis,
+                            int64_t n2, int64_t first_index, int64_t n_points, double *d_dbeta1, double *d_dbeta2) {
+    return dbeta_pairs_dev<double>(stream, orders, n_orders, beta, n_beta, omega_d, d_Omega1_axis, n1, d_Omega2_axis, n2,
+                                   first_index, n_points, d_dbeta1, d_dbeta2);
+}
+int psa_dbeta_pairs_f32_dev(void *stream, const int32_t *orders, int n_orders, const double *beta, int n_beta,
+                            double omega_d, const double *d_Omega1_axis, int64_t n1, const double *d_Omega2_axis,
+                            int64_t n2, int64_t first_index, int64_t n_points, float *d_dbeta1, float *d_dbeta2) {
+    return dbeta_pairs_dev<float>(stream, orders, n_orders, beta, n_beta, omega_d, d_Omega1_axis, n1, d_Omega2_axis, n2,
+                                  first_index, n_points, d_dbeta1, d_dbeta2);
+}
+
+int psa_dbeta_grid_f64(int device, int method, const int32_t *orders, int n_orders, int max_order, const double *beta,
+                       int n_beta, double omega_ref, double two_pi_c, double atol, double rtol, double lambda1_m,
+                       const double *lambda2_axis, int64_t n2, const double *lambda3_axis, int64_t n3,
+                       int64_t first_index, int64_t n_points, double *dbeta, uint8_t *valid) {
+    if (n_points < 0 || n2 <= 0 || n3 <= 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0 and the axes non-empty");
+    if (!lambda2_axis || !lambda3_axis || (n_points > 0 && !dbeta)) return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    int rc = check_device(device, "the dbeta producer");
+    if (rc != PSA_OK) return rc;
+    if (n_points == 0) return PSA_OK;
+    DeviceScope scope;
+    DevBuf b2, b3, bo, bv;
+    HIP_TRY(scope.enter(device));
+    HIP_TRY(b2.alloc((size_t)n2 * 8)); HIP_TRY(b3.alloc((size_t)n3 * 8)); HIP_TRY(bo.alloc((size_t)n_points * 8));
+    if (valid) HIP_TRY(bv.alloc((size_t)n_points));
+    HIP_TRY(hipMemcpy(b2.p, lambda2_axis, (size_t)n2 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b3.p, lambda3_axis, (size_t)n3 * 8, hipMemcpyHostToDevice));
+    rc = psa_dbeta_grid_f64_dev(nullptr, method, orders, n_orders, max_order, beta, n_beta, omega_ref, two_pi_c, atol, rtol,
+                                lambda1_m, b2.as<double>(), n2, b3.as<double>(), n3, first_index, n_points,
+                                bo.as<double>(), valid ? bv.as<uint8_t>() : nullptr);
     if (rc != PSA_OK) goto done;
-    if (gain_out && N) HIP_TRY(hipMemcpy(gain_out, bg.p, N * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(best_index, bi.p, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(best_gain, bbg.p, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(n_finite, bn.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dbeta, bo.p, (size_t)n_points * 8, hipMemcpyDeviceToHost));
+    if (valid) HIP_TRY(hipMemcpy(valid, bv.p, (size_t)n_points, hipMemcpyDeviceToHost));
+done:
+    return rc;
+}
+
+int psa_dbeta_pairs_f64(int device, const int32_t *orders, int n_orders, const double *beta, int n_beta, double omega_d,
+                        const double *Omega1_axis, int64_t n1, const double *Omega2_axis, int64_t n2,
+                        int64_t first_index, int64_t n_points, double *dbeta1, double *dbeta2) {
+    if (n_points < 0 || n1 <= 0 || n2 <= 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0 and the axes non-empty");
+    if (!Omega1_axis || !Omega2_axis || (n_points > 0 && (!dbeta1 || !dbeta2))) return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    int rc = check_device(device, "the dbeta producer");
+    if (rc != PSA_OK) return rc;
+    if (n_points == 0) return PSA_OK;
+    DeviceScope scope;
+    DevBuf b1, b2, o1, o2;
+    HIP_TRY(scope.enter(device));
+    HIP_TRY(b1.alloc((size_t)n1 * 8)); HIP_TRY(b2.alloc((size_t)n2 * 8));
+    HIP_TRY(o1.alloc((size_t)n_points * 8)); HIP_TRY(o2.alloc((size_t)n_points * 8));
+    HIP_TRY(hipMemcpy(b1.p, Omega1_axis, (size_t)n1 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b2.p, Omega2_axis, (size_t)n2 * 8, hipMemcpyHostToDevice));
+    rc = psa_dbeta_pairs_f64_dev(nullptr, orders, n_orders, beta, n_beta, omega_d, b1.as<double>(), n1, b2.as<double>(), n2,
+                                 first_index, n_points, o1.as<double>(), o2.as<double>());
+    if (rc != PSA_OK) goto done;
+    HIP_TRY(hipMemcpy(dbeta1, o1.p, (size_t)n_points * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dbeta2, o2.p, (size_t)n_points * 8, hipMemcpyDeviceToHost));
 done:
     return rc;
 }

@@ -148,8 +148,11 @@ __device__ __forceinline__ bool any_nonfinite(const T (&y)[NC]) {
 // ds_read/ds_write_b64 touches 64 consecutive 8-byte words: conflict-free).  It exists for the A/B in DESIGN.md
 // section 5: the register-resident form wins because the LDS round trips buy nothing (no data is shared
 // between lanes) and cost issue slots next to an already saturated FP64 pipe.
+#ifndef PSA_SWEEP_KERNEL_ATTR   // A/B hook (tools/ab_build.sh): e.g. -DPSA_SWEEP_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(3)))'
+#define PSA_SWEEP_KERNEL_ATTR
+#endif
 template <typename T, int NW, int CHECK, bool TRAJ, int BLOCK, bool LDS = false, bool LOSS = true>
-__global__ void __launch_bounds__(BLOCK) rk4_sweep_kernel(const SweepArgs<T> A) {
+__global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(const SweepArgs<T> A) {
     constexpr int NC = 2 * NW;
     constexpr int NP = (NW - 2) / 2;
     constexpr int RESYNC = Phase<T>::RESYNC;

@@ -1,0 +1,267 @@
+// psa_rk4_split_kernel.inc.h -- float64 RK4 sweep with TWO LANES PER SWEEP POINT (gfx950).
+//
+// Why: the sweep is FP64-issue bound and the z-loop is sequential, so a sweep smaller than the chip
+// (N <= 32 768 points = 512 waves for 1 024 SIMDs: BASELINE config 5's per-GPU shard; config 1's single point)
+// leaves SIMDs idle that no amount of occupancy can use.  Here a point's waves are divided between an even
+// lane and its odd neighbour, which halves the dependent instruction stream per lane:
+//
+//   4 waves   even lane: (u, v) = (A_p1, A_p2)            odd lane: (u, v) = (A_s, A_i)
+//             dA_u/dz = (-alpha/2 + i*gamma*f_u) A_u + i*conj(A_v) * F,    F = E_lane * Q
+//             Q = (A_u A_v) of the PARTNER lane,  E_lane = 2*gamma*exp(+i*dbeta*z) (even) | its conjugate (odd)
+//             -- the pumps are driven by E*(A_s A_i), the sidebands by conj(E)*(A_p1 A_p2)  (yaman_model.py:174-181),
+//             so both lanes run the SAME instruction stream with a lane-dependent sign of dbeta.
+//   6 waves   even lane: (w, u, v) = (A_p1, A_s1, A_i1), dbeta_1      odd lane: (A_p2, A_s2, A_i2), dbeta_2
+//             dA_w/dz = (...) A_w + i*conj(W) * (t + T),   t = E_own * (A_u A_v),  W, T = the partner's A_w, t
+//             dA_u/dz = (...) A_u + i*conj(A_v) * conj(E_own) * (A_w W)            (same for v with u)
+//   f_j = 2*S - |A_j|^2 with S = own partial sum + the partner's.
+//
+// Values cross between the two lanes with DPP quad_perm:[1,0,3,2] moves (two v_mov_b32_dpp per double: gfx950's
+// DP ALU accepts no quad_perm, so the exchange cannot be folded into the consuming v_fma_f64).  Per RHS evaluation:
+// 4 waves 39 instructions (6 of them moves) instead of 64; 6 waves 65 (10 moves) instead of 100.
+// Same RK4 regrouping, phase recurrence, save / NaN semantics as rk4_sweep_kernel -- see that file.
+#pragma once
+#include "psa_rk4_kernel.inc.h"
+
+namespace psa {
+
+// the value the neighbouring lane (lane ^ 1) holds
+__device__ __forceinline__ double from_partner(const double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// out = base + c * dA/dz(a) for the lane's own waves (stage coefficient folded into g, tg, ha, E as in yaman_stage).
+// NL = waves per lane (2 | 3); a = [Re, Im] x NL in the lane's order given above.
+template <int NL, bool LOSS>
+__device__ __forceinline__ void split_stage(const double (&a)[2 * NL], const double (&base)[2 * NL], const double Er,
+                                            const double Ei, const double g, const double tg, const double ha,
+                                            double (&out)[2 * NL]) {
+    double p[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) p[j] = fma_(a[2 * j], a[2 * j], a[2 * j + 1] * a[2 * j + 1]);
+    double sl = p[0] + p[1];
+    if constexpr (NL == 3) sl += p[2];
+    const double s = sl + from_partner(sl);
+    const double gs = tg * s;
+    double gj[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) gj[j] = fma_(-g, p[j], gs);
+    auto link = [&](const double gsig, const double v, const int c) -> double {
+        if constexpr (LOSS) return fma_(gsig, v, fma_(ha, a[c], base[c]));
+        else return fma_(gsig, v, base[c]);
+    };
+    // the last two waves of the lane are a pair (u, v) coupled through one driving term F
+    constexpr int U = 2 * (NL - 2);
+    const double xu = a[U], yu = a[U + 1], xv = a[U + 2], yv = a[U + 3];
+    const double qr = fma_(xu, xv, -(yu * yv)), qi = fma_(xu, yv, yu * xv);  // A_u * A_v
+    double Fr, Fi;
+    if constexpr (NL == 2) {
+        const double Qr = from_partner(qr), Qi = from_partner(qi);
+        Fr = fma_(Er, Qr, -(Ei * Qi));
+        Fi = fma_(Er, Qi, Ei * Qr);
+    } else {
+        const double xw = a[0], yw = a[1];
+        const double Xw = from_partner(xw), Yw = from_partner(yw);  // the other pump
+        const double tr = fma_(Er, qr, -(Ei * qi)), ti = fma_(Er, qi, Ei * qr);  // E_own * (A_u A_v)
+        const double Fpr = tr + from_partner(tr), Fpi = ti + from_partner(ti);  // sum over both pairs
+        const double q12r = fma_(xw, Xw, -(yw * Yw)), q12i = fma_(xw, Yw, yw * Xw);  // A_p1 * A_p2
+        Fr = fma_(Er, q12r, Ei * q12i);  // conj(E_own) * (A_p1 A_p2)
+        Fi = fma_(Er, q12i, -(Ei * q12r));
+        // pump: (ha + i g_w) A_w + i conj(W) Fp
+        out[0] = fma_(Yw, Fpr, fma_(-Xw, Fpi, link(-gj[0], yw, 0)));
+        out[1] = fma_(Xw, Fpr, fma_(Yw, Fpi, link(gj[0], xw, 1)));
+    }
+    const double gu = gj[NL - 2], gv = gj[NL - 1];
+    out[U] = fma_(yv, Fr, fma_(-xv, Fi, link(-gu, yu, U)));
+    out[U + 1] = fma_(xv, Fr, fma_(yv, Fi, link(gu, xu, U + 1)));
+    out[U + 2] = fma_(yu, Fr, fma_(-xu, Fi, link(-gv, yv, U + 2)));
+    out[U + 3] = fma_(xu, Fr, fma_(yu, Fi, link(gv, xv, U + 3)));
+}
+
+template <int NW, int CHECK, bool TRAJ, int BLOCK, bool LOSS>
+__global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<double> A) {
+    constexpr int NL = NW / 2;    // waves per lane
+    constexpr int NC = 2 * NL;    // real components per lane
+    constexpr int RESYNC = Phase<double>::RESYNC;
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long idx = gid >> 1;   // sweep point: lanes 2k and 2k+1 of a wave share one
+    const int role = (int)(gid & 1);
+    const long long N = A.n_points;
+    if (idx >= N) return;             // both lanes of a pair leave together
+
+    // which global wave each of the lane's waves is
+    int wave_of[NL];
+    if constexpr (NL == 2) {
+        wave_of[0] = 2 * role;
+        wave_of[1] = 2 * role + 1;
+    } else {
+        wave_of[0] = role;
+        wave_of[1] = 2 + 2 * role;
+        wave_of[2] = 3 + 2 * role;
+    }
+    const bool owns_signal = (NL == 2) ? (role == 1) : (role == 0);   // wave index 2, the gain summary's wave
+    constexpr int SIG = (NL == 2) ? 0 : 2;                            // its component offset in the owning lane
+
+    double y[NC];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        y[2 * j] = A.a0[(long long)(2 * wave_of[j]) * A.a0_ld + idx * A.a0_stride];
+        y[2 * j + 1] = A.a0[(long long)(2 * wave_of[j] + 1) * A.a0_ld + idx * A.a0_stride];
+    }
+    const double g = A.gamma[idx * A.gamma_stride];
+    const double tg = g + g;
+    const double ha = -0.5 * A.alpha[idx * A.alpha_stride];
+    // the lane's phase rate: 4 waves +dbeta (pumps) | -dbeta (sidebands: conj(E)); 6 waves the own pair's dbeta_k
+    double dbd;
+    if constexpr (NL == 2) dbd = role ? -A.dbeta[idx] : A.dbeta[idx];
+    else dbd = role ? A.dbeta2[idx] : A.dbeta[idx];
+
+    const double hd = A.z_max / (double)A.n_steps;
+    const double hh = 0.5 * hd;
+    const double g_d = hh * g, tg_d = hh * tg, ha_d = hh * ha;
+    const double g_h = hd * g, tg_h = hd * tg, ha_h = hd * ha;
+    const double third = 1.0 / 3.0;
+    const double e_amp = tg_d;
+
+    double rc, rs, Er = e_amp, Ei = 0.0;
+    Phase<double>::eval(dbd * (0.5 * hd), rc, rs);
+
+    double pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
+    double pm = pe;
+    long long bad = -1;
+    // any component of the POINT non-finite (own lane's or the partner's)
+    auto point_nonfinite = [&]() -> bool {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t = fma_(y[c], 0.0, t);
+        t += from_partner(t);
+        return t != t;
+    };
+
+    const int se = A.save_every;
+    const int n_rows = A.n_steps / se;
+    const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;
+
+    using Pair = typename PairOf<double>::type;
+    auto store_traj_row = [&](const int r) {
+        Pair *dst = reinterpret_cast<Pair *>(A.traj) + (long long)r * NW * N + idx;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            __builtin_nontemporal_store(Pair{y[2 * j], y[2 * j + 1]}, dst + (long long)wave_of[j] * N);
+    };
+    auto store_a_end = [&]() {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            A.a_end[(long long)(2 * wave_of[j]) * N + idx] = y[2 * j];
+            A.a_end[(long long)(2 * wave_of[j] + 1) * N + idx] = y[2 * j + 1];
+        }
+    };
+    if constexpr (TRAJ) store_traj_row(0);
+    if (n_rows == 0) store_a_end();
+
+    // one RK4 step, regrouped exactly as rk4_step_reg of rk4_sweep_kernel (integrators.py:54-59)
+    auto rk4_step = [&](const int step_index) {
+        double Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
+        split_stage<NL, LOSS>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);
+        rotate(Er, Ei, rc, rs);  // z + h/2
+        split_stage<NL, LOSS>(Y2, y, Er, Ei, g_d, tg_d, ha_d, Y3);
+        const double E2r = Er + Er, E2i = Ei + Ei;
+        split_stage<NL, LOSS>(Y3, y, E2r, E2i, g_h, tg_h, ha_h, Y4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t[c] = fma_(2.0, Y3[c], fma_(-4.0, y[c], Y2[c])) + Y4[c];
+        rotate(Er, Ei, rc, rs);  // z + h
+        split_stage<NL, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
+        if constexpr (CHECK == CHECK_EXACT) {
+            if (bad < 0 && point_nonfinite()) bad = step_index;
+        }
+    };
+
+    constexpr int CHUNK = RESYNC / 2;
+    int i = 0, since_seed = RESYNC, row = 0;
+    int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    while (i < n_run) {
+        if (since_seed >= RESYNC) {
+            double c, s;
+            Phase<double>::eval(dbd * ((double)i * hd), c, s);
+            Er = e_amp * c;
+            Ei = e_amp * s;
+            since_seed = 0;
+        }
+        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
+        end = end < next_save ? end : next_save;
+        const int m = end - i;
+        int j = 0;
+        for (; j + 2 <= m; j += 2) {
+            rk4_step(i + j);
+            rk4_step(i + j + 1);
+        }
+        if (j < m) rk4_step(i + j);
+        i = end;
+        since_seed += m;
+        if (i == next_save) {
+            ++row;
+            pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
+            pm = (pe > pm || pe != pe) ? pe : pm;
+            if constexpr (CHECK == CHECK_BLOCK) {
+                if (bad < 0 && point_nonfinite()) bad = i - 1;
+            }
+            if constexpr (TRAJ) store_traj_row(row);
+            if (row == n_rows) {
+                store_a_end();
+                next_save = 0x7fffffff;
+            } else {
+                next_save += se;
+            }
+        }
+    }
+    if constexpr (CHECK == CHECK_BLOCK) {
+        if (bad < 0 && n_run > 0 && point_nonfinite()) bad = n_run - 1;
+    }
+    if (owns_signal) {
+        A.p_end[idx] = pe;
+        A.p_max[idx] = pm;
+    }
+    if (role == 0) A.first_bad[idx] = bad;
+}
+
+template <int NW, int CHECK, bool TRAJ>
+static hipError_t launch_split_one(hipStream_t s, bool lossless, int block, const SweepArgs<double> &a) {
+    const long long lanes = 2 * a.n_points;
+    if (block == 256) {
+        const dim3 grid((unsigned)((lanes + 255) / 256));
+        if (lossless) hipLaunchKernelGGL((rk4_sweep_split_kernel<NW, CHECK, TRAJ, 256, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rk4_sweep_split_kernel<NW, CHECK, TRAJ, 256, true>), grid, dim3(256), 0, s, a);
+    } else {
+        const dim3 grid((unsigned)((lanes + 63) / 64));
+        if (lossless) hipLaunchKernelGGL((rk4_sweep_split_kernel<NW, CHECK, TRAJ, 64, false>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((rk4_sweep_split_kernel<NW, CHECK, TRAJ, 64, true>), grid, dim3(64), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int NW>
+static hipError_t launch_split_nw(hipStream_t s, int check, bool lossless, int block, const SweepArgs<double> &a) {
+    const bool traj = a.traj != nullptr;
+    switch (check) {
+        case CHECK_NONE:
+            return traj ? launch_split_one<NW, CHECK_NONE, true>(s, lossless, block, a) : launch_split_one<NW, CHECK_NONE, false>(s, lossless, block, a);
+        case CHECK_BLOCK:
+            return traj ? launch_split_one<NW, CHECK_BLOCK, true>(s, lossless, block, a) : launch_split_one<NW, CHECK_BLOCK, false>(s, lossless, block, a);
+        default:
+            return traj ? launch_split_one<NW, CHECK_EXACT, true>(s, lossless, block, a) : launch_split_one<NW, CHECK_EXACT, false>(s, lossless, block, a);
+    }
+}
+
+// block: 64 (one wave per workgroup: a sweep of few waves is spread over as many CUs as it has waves) or 256 (four waves
+// per workgroup land on the four SIMDs of one CU: the placement that gives every wave its own SIMD when the sweep fills
+// the chip -- 1 024 single-wave workgroups measured 12 % slower at N = 32 768 because some SIMDs received two).
+static hipError_t launch_sweep_split(hipStream_t s, int n_waves, int check, bool lossless, int block, const SweepArgs<double> &a) {
+    if (a.n_points == 0) return hipSuccess;
+    return n_waves == 4 ? launch_split_nw<4>(s, check, lossless, block, a) : launch_split_nw<6>(s, check, lossless, block, a);
+}
+
+}  // namespace psa

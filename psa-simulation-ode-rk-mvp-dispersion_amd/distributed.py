@@ -3,12 +3,20 @@
 Sweep points are independent initial-value problems (the reference's loop body has no cross-iteration state,
 scan_mismtach.py:694-738), so the path shards with NO data-path collective: rank r integrates the contiguous
 block ``shard_bounds(N, world, r)`` on its own GPU.  The only exchange is one ``all_gather`` of the per-point
-output record (RCCL over xGMI when the process group is ``nccl``; ``gloo`` on CPU tensors in the tests):
+output record (RCCL over xGMI when the process group is ``nccl``; ``gloo`` on CPU tensors in the tests).
 
-    record[r] = [Re/Im A_end (2*n_waves rows) | p_sig_end | p_sig_max | first_bad_step (int64 bits)]   x n_local
+The record is the flat byte image the sweep kernel itself writes (``RecordLayout``), for n points of a sweep with
+n_waves waves in float64 or float32 (element size es):
 
-i.e. 88 B per point for 4 waves -- a few MB per rank, latency-bound on 7 x ~153 GB/s links, so one flat
-all_gather is the right collective (no bucketing, no ring tuning).
+    [ A_end SoA: 2*n_waves rows x n x es | p_sig_end n x es | p_sig_max n x es | first_bad_step n x int64 ]
+
+i.e. 88 B per point for 4 waves in float64, 48 B in float32, 120 B for 6 waves -- a few MB per rank, latency-bound on
+7 x ~153 GB/s links, so one flat all_gather is the right collective (no bucketing, no ring tuning).  It travels as
+int64 words (a pure bit copy: first_bad_step = -1 would be a NaN pattern as a float).  Ranks whose block is one point
+shorter (N % world != 0) pad their image with zero words to the widest block, so every rank contributes equally.
+
+Inputs need not travel at all: ``DeviceSweep.fill_dbeta_grid`` / ``fill_dbeta_pairs`` make each rank generate the dbeta
+of its own block on its own GPU from the grid definition (two short axes), see csrc/psa_dbeta.hip.
 
 One process per GPU (``torchrun`` / ``python -m torch.distributed.run``).  ``import torch`` happens before
 ``libpsa_hip.so`` is loaded so both share one HIP runtime in the process.
@@ -24,7 +32,7 @@ import torch.distributed as dist
 from . import _native
 from .sweep import SweepResult
 
-__all__ = ["shard_bounds", "record_rows", "pack_record", "unpack_records", "sweep_sharded", "DeviceSweep"]
+__all__ = ["shard_bounds", "RecordLayout", "unpack_gathered", "sweep_sharded", "DeviceSweep"]
 
 
 def shard_bounds(n_points: int, world: int, rank: int) -> Tuple[int, int]:
@@ -36,49 +44,96 @@ def shard_bounds(n_points: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def record_rows(n_waves: int) -> int:
-    return 2 * n_waves + 3
+class RecordLayout:
+    """Byte layout of one shard's output record for (n_waves, dtype); see the module docstring."""
+
+    def __init__(self, n_waves: int, dtype=np.float64):
+        if n_waves not in (4, 6):
+            raise ValueError("n_waves must be 4 or 6")
+        self.n_waves = int(n_waves)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("dtype must be float64 or float32")
+        self.es = self.dtype.itemsize
+        self.cdtype = np.complex128 if self.es == 8 else np.complex64
+        self.float_rows = 2 * self.n_waves + 2
+
+    def bytes_per_point(self) -> int:
+        return self.float_rows * self.es + 8
+
+    def nbytes(self, n: int) -> int:            # always a whole number of int64 words: (2*nw + 2) is even
+        return int(n) * self.bytes_per_point()
+
+    def words(self, n: int) -> int:
+        return self.nbytes(n) // 8
+
+    def offsets(self, n: int) -> dict:
+        """Byte offsets of the parts inside a record of n points."""
+        n, nw, es = int(n), self.n_waves, self.es
+        return dict(a_end=0, p_end=2 * nw * n * es, p_max=(2 * nw + 1) * n * es, first_bad=(2 * nw + 2) * n * es)
+
+    def pack(self, a_end: np.ndarray, p_end: np.ndarray, p_max: np.ndarray, first_bad: np.ndarray,
+             pad_to: Optional[int] = None) -> np.ndarray:
+        """Host arrays -> the int64-word image (zero-padded to the size of a ``pad_to``-point record)."""
+        a_end = np.asarray(a_end)
+        n = a_end.shape[0]
+        if a_end.shape != (n, self.n_waves):
+            raise ValueError(f"a_end must be (n, {self.n_waves}), got {a_end.shape}")
+        buf = np.zeros(self.nbytes(max(n, pad_to or 0)), dtype=np.uint8)
+        off = self.offsets(n)
+        soa = np.empty((2 * self.n_waves, n), dtype=self.dtype)
+        soa[0::2] = a_end.real.T
+        soa[1::2] = a_end.imag.T
+        buf[0:off["p_end"]] = soa.reshape(-1).view(np.uint8)
+        buf[off["p_end"]:off["p_max"]] = np.ascontiguousarray(p_end, dtype=self.dtype).view(np.uint8)
+        buf[off["p_max"]:off["first_bad"]] = np.ascontiguousarray(p_max, dtype=self.dtype).view(np.uint8)
+        buf[off["first_bad"]:self.nbytes(n)] = np.ascontiguousarray(first_bad, dtype=np.int64).view(np.uint8)
+        return buf.view(np.int64)
+
+    def unpack(self, words: np.ndarray, n: int):
+        """The int64-word image of an n-point record (trailing padding ignored) -> (a_end (n, nw) complex, p_end, p_max,
+        first_bad int64)."""
+        n = int(n)
+        buf = np.ascontiguousarray(words).reshape(-1).view(np.uint8)
+        off = self.offsets(n)
+        soa = buf[0:off["p_end"]].view(self.dtype).reshape(2 * self.n_waves, n)
+        a_end = np.empty((n, self.n_waves), dtype=self.cdtype)
+        a_end.real = soa[0::2].T
+        a_end.imag = soa[1::2].T
+        p_end = buf[off["p_end"]:off["p_max"]].view(self.dtype).copy()
+        p_max = buf[off["p_max"]:off["first_bad"]].view(self.dtype).copy()
+        first_bad = buf[off["first_bad"]:self.nbytes(n)].view(np.int64).copy()
+        return a_end, p_end, p_max, first_bad
 
 
-def pack_record(a_end: np.ndarray, p_end: np.ndarray, p_max: np.ndarray, first_bad: np.ndarray, width: int) -> np.ndarray:
-    """(rows, width) float64, zero-padded on the right; first_bad travels as raw int64 bits in the last row."""
-    n, nw = a_end.shape
-    rec = np.zeros((record_rows(nw), width), dtype=np.float64)
-    rec[0:2 * nw:2, :n] = a_end.real.T
-    rec[1:2 * nw:2, :n] = a_end.imag.T
-    rec[2 * nw, :n] = p_end
-    rec[2 * nw + 1, :n] = p_max
-    rec[2 * nw + 2, :n] = np.ascontiguousarray(first_bad, dtype=np.int64).view(np.float64)
-    return rec
-
-
-def unpack_records(gathered: np.ndarray, n_points: int, world: int, n_waves: int):
-    """gathered (world, rows, width) -> (a_end (N, nw) c128, p_end, p_max, first_bad int64), shards trimmed."""
-    a_parts, pe, pm, fb = [], [], [], []
-    for r in range(world):
-        lo, hi = shard_bounds(n_points, world, r)
-        n = hi - lo
-        rec = gathered[r]
-        a_parts.append((rec[0:2 * n_waves:2, :n] + 1j * rec[1:2 * n_waves:2, :n]).T)
-        pe.append(rec[2 * n_waves, :n])
-        pm.append(rec[2 * n_waves + 1, :n])
-        fb.append(np.ascontiguousarray(rec[2 * n_waves + 2, :n]).view(np.int64))
-    return (np.concatenate(a_parts), np.concatenate(pe), np.concatenate(pm), np.concatenate(fb))
+def unpack_gathered(layout: RecordLayout, gathered: np.ndarray, n_points: int, world: int):
+    """gathered (world, words(width)) int64 -> the whole sweep's (a_end, p_end, p_max, first_bad), shards trimmed."""
+    parts = [layout.unpack(gathered[r], shard_bounds(n_points, world, r)[1] - shard_bounds(n_points, world, r)[0])
+             for r in range(world)]
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
 
 
 def _native_executor(dbeta, **kw):
     return _native.sweep_host(dbeta, **kw)
 
 
+def _all_gather_words(t_local: torch.Tensor, world: int, group) -> torch.Tensor:
+    """The single collective of the path: every rank contributes the same number of int64 words."""
+    out = torch.empty(world * t_local.numel(), dtype=torch.int64, device=t_local.device)
+    dist.all_gather_into_tensor(out, t_local, group=group)
+    return out.view(world, t_local.numel())
+
+
 def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, gamma, alpha, a0, dbeta2=None,
-                  check_nan: bool = True, group=None, device: Optional[int] = None,
+                  check_nan: bool = True, dtype=np.float64, group=None, device: Optional[int] = None,
                   executor: Optional[Callable[..., dict]] = None) -> SweepResult:
     """Every rank passes the SAME full-sweep arguments and receives the full result.
 
     Per-point arrays (dbeta, optionally gamma / alpha / a0 / dbeta2 with leading dimension N) are sliced to the
-    rank's block; scalars and a single a0 are broadcast.  ``executor(dbeta_local, **kw) -> dict`` runs the local
-    shard; the default is the HIP kernel on ``device`` (default: LOCAL_RANK-th GPU).  Tests inject the CPU oracle
-    here to exercise the shard/gather logic under ``gloo`` without a GPU.
+    rank's block; scalars and a single a0 are broadcast.  ``dtype`` float64 | float32 selects the kernel and the record
+    (BASELINE config 4 is float32); six-column ``a0`` + ``dbeta2`` select the 6-wave model (config 5).
+    ``executor(dbeta_local, **kw) -> dict`` runs the local shard; the default is the HIP kernel on ``device`` (default:
+    LOCAL_RANK-th GPU).  Tests inject the CPU oracle here to exercise the shard/gather logic under ``gloo`` without a GPU.
     """
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised (launch with torchrun, one process per GPU)")
@@ -93,10 +148,13 @@ def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, ga
 
     a0 = np.asarray(a0)
     nw = int(a0.shape[-1])
+    layout = RecordLayout(nw, dtype)
     kw = dict(n_steps=int(n_steps), z_max=float(z_max), save_every=int(save_every), gamma=cut(gamma, 1),
               alpha=cut(alpha, 1), a0=cut(a0, 2), check_nan=bool(check_nan))
     if dbeta2 is not None:
         kw["dbeta2"] = cut(dbeta2, 1)
+    if layout.es == 4:
+        kw["dtype"] = np.float32
     if executor is None:
         executor = _native_executor
         if device is None:
@@ -104,96 +162,155 @@ def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, ga
             device = int(os.environ.get("LOCAL_RANK", rank))
         kw["device"] = int(device) % max(1, _native.device_count())
     local = executor(dbeta[lo:hi], **kw) if hi > lo else dict(
-        a_end=np.zeros((0, nw), complex), p_end=np.zeros(0), p_max=np.zeros(0), first_bad_step=np.zeros(0, np.int64))
+        a_end=np.zeros((0, nw), layout.cdtype), p_end=np.zeros(0, layout.dtype), p_max=np.zeros(0, layout.dtype),
+        first_bad_step=np.zeros(0, np.int64))
 
     width = (N + world - 1) // world                     # widest shard; shorter ones are zero-padded
-    rec = pack_record(local["a_end"], local["p_end"], local["p_max"], local["first_bad_step"], width)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    t_local = torch.from_numpy(rec).to(dev)
-    # shipped as int64 words: a pure bit copy (first_bad_step = -1 is a NaN pattern when read as float64)
-    t_all = torch.empty(world * t_local.numel(), dtype=torch.int64, device=dev)   # flat: rank-major concatenation
-    dist.all_gather_into_tensor(t_all, t_local.reshape(-1).view(torch.int64), group=group)   # the single collective
-    gathered = t_all.view(torch.float64).cpu().numpy().reshape((world,) + tuple(t_local.shape))
-    a_end, p_end, p_max, first_bad = unpack_records(gathered, N, world, nw)
+    words = layout.pack(local["a_end"], local["p_end"], local["p_max"], local["first_bad_step"], pad_to=width)
+    if dist.get_backend(group) == "nccl":
+        # the collective runs on the GPU that computed the shard, also for a rank whose block is empty
+        dev_index = kw.get("device", int(device) if device is not None else torch.cuda.current_device())
+        dev = torch.device("cuda", int(dev_index))
+        with torch.cuda.device(dev):
+            gathered = _all_gather_words(torch.from_numpy(words).to(dev), world, group).cpu().numpy()
+    else:
+        gathered = _all_gather_words(torch.from_numpy(words), world, group).numpy()
+    a_end, p_end, p_max, first_bad = unpack_gathered(layout, gathered, N, world)
     return SweepResult(a_end, p_end, p_max, first_bad, int(n_steps), int(save_every),
                        float(local.get("elapsed_ms", 0.0)))
+
+
+_TORCH_DTYPE = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}
 
 
 class DeviceSweep:
     """A rank's shard kept resident in HBM (torch tensors), launched on torch's current stream.
 
-    Used by ``bench.py`` and by callers that chain sweeps without host round trips.  Layout is the SoA device
-    layout of ``psa_rk4_sweep_f64_dev``; ``record`` is the (2*nw + 3, n_local) float64 tensor that
-    ``all_gather_into_tensor`` ships (first_bad_step in the last row as int64 bits).
+    Used by ``bench.py`` and by callers that chain sweeps without host round trips: float64 or float32, 4 or 6 waves
+    (``a0`` of length 6 + ``dbeta2_local``).  Layout is the SoA device layout of ``psa_rk4_sweep_f64_dev`` / ``_f32_dev``;
+    ``record`` is the int64-word image of ``RecordLayout`` that the kernel writes into directly and that
+    ``gather()`` ships -- no packing pass.  ``pad_to`` (the widest block of the sharded sweep) makes records of ragged
+    shards equally long.  dbeta comes either from the host (``dbeta_local``) or is generated on this GPU
+    (``n_local`` + ``fill_dbeta_grid`` / ``fill_dbeta_pairs``).
     """
 
-    def __init__(self, dbeta_local: np.ndarray, *, n_steps: int, z_max: float, save_every: int, gamma: float,
-                 alpha: float, a0: np.ndarray, check_nan: bool = True, exact_step: bool = False,
-                 device: Optional[torch.device] = None, extra_flags: int = 0):
+    def __init__(self, dbeta_local: Optional[np.ndarray] = None, *, n_steps: int, z_max: float, save_every: int,
+                 gamma: float, alpha: float, a0: np.ndarray, dbeta2_local: Optional[np.ndarray] = None,
+                 n_local: Optional[int] = None, dtype=np.float64, check_nan: bool = True, exact_step: bool = False,
+                 device: Optional[torch.device] = None, extra_flags: int = 0, pad_to: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceSweep needs a GPU: libpsa_hip has no CPU fallback")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         a0 = np.asarray(a0, dtype=np.complex128)
-        if a0.ndim != 1 or a0.shape[0] != 4:
-            raise ValueError("DeviceSweep: a0 must be one (4,) complex vector (broadcast to every point)")
-        self.n_waves, self.n_local = 4, int(np.asarray(dbeta_local).shape[0])
+        if a0.ndim != 1 or a0.shape[0] not in (4, 6):
+            raise ValueError("DeviceSweep: a0 must be one (4,) or (6,) complex vector (broadcast to every point)")
+        self.n_waves = int(a0.shape[0])
+        self.layout = RecordLayout(self.n_waves, dtype)
+        self.np_dtype = self.layout.dtype
+        self.tdtype = _TORCH_DTYPE[self.np_dtype]
+        if dbeta_local is None and n_local is None:
+            raise ValueError("give dbeta_local, or n_local and fill the mismatch on the device")
+        self.n_local = int(np.asarray(dbeta_local).shape[0]) if dbeta_local is not None else int(n_local)
         self.n_steps, self.z_max, self.save_every = int(n_steps), float(z_max), int(save_every)
-        f64 = dict(dtype=torch.float64, device=self.device)
-        self.dbeta = torch.as_tensor(np.ascontiguousarray(dbeta_local, dtype=np.float64)).to(self.device)
-        self.gamma = torch.tensor([float(gamma)], **f64)
-        self.alpha = torch.tensor([float(alpha)], **f64)
-        self.a0_soa = torch.tensor(np.stack([a0.real, a0.imag], 1).reshape(-1, 1), **f64).contiguous()   # [8][1]
-        self.record = torch.zeros((record_rows(4), self.n_local), **f64)
-        self.traj = None    # optional [n_saved][4][n_local][2] trajectory buffer (enable_trajectory)
+        opts = dict(dtype=self.tdtype, device=self.device)
+
+        def to_dev(x):
+            return torch.as_tensor(np.ascontiguousarray(x, dtype=self.np_dtype)).to(self.device)
+
+        self.dbeta = to_dev(dbeta_local) if dbeta_local is not None else torch.zeros(self.n_local, **opts)
+        self.dbeta2 = None
+        if self.n_waves == 6:
+            if dbeta_local is not None and dbeta2_local is None:
+                raise ValueError("six waves need dbeta2_local")
+            self.dbeta2 = to_dev(dbeta2_local) if dbeta2_local is not None else torch.zeros(self.n_local, **opts)
+            if self.dbeta2.shape != self.dbeta.shape:
+                raise ValueError("dbeta2_local must match dbeta_local")
+        elif dbeta2_local is not None:
+            raise ValueError("dbeta2_local is only meaningful for six waves")
+        self.gamma = torch.tensor([float(gamma)], **opts)
+        self.alpha = torch.tensor([float(alpha)], **opts)
+        self.a0_soa = torch.tensor(np.stack([a0.real, a0.imag], 1).reshape(-1, 1), **opts).contiguous()   # [2*nw][1]
+        self.pad_to = max(self.n_local, int(pad_to or 0))
+        self.record = torch.zeros(self.layout.words(self.pad_to), dtype=torch.int64, device=self.device)
+        self.traj = None    # optional [n_saved][n_waves][n_local][2] trajectory buffer (enable_trajectory)
         self.flags = (_native.BCAST_GAMMA | _native.BCAST_ALPHA | _native.BCAST_A0 | int(extra_flags)
                       | (_native.OPT_CHECK_NAN if check_nan else 0) | (_native.OPT_EXACT_STEP if exact_step else 0)
                       | (_native.OPT_LOSSLESS if float(alpha) == 0.0 else 0))
+        self._axes = {}
 
+    # ---- record parts as device addresses -------------------------------------------------------------------
+    def _part(self, name: str) -> int:
+        return self.record.data_ptr() + self.layout.offsets(self.n_local)[name]
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- dbeta generated on this GPU ---------------------------------------------------------------------------
+    def _axis(self, key: str, values) -> torch.Tensor:
+        t = torch.as_tensor(np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64)).to(self.device)
+        self._axes[key] = t      # kept alive: the launch is asynchronous
+        return t
+
+    def fill_dbeta_grid(self, model: dict, lambda1_m: float, lambda2_axis, lambda3_axis, *, first: int) -> None:
+        """This rank's block [first, first + n_local) of the flattened lambda_p2 x lambda_signal grid, produced by
+        ``psa_dbeta_grid_*_dev`` on torch's current stream (invalid plans become NaN -> a NaN gain downstream)."""
+        if self.n_waves != 4:
+            raise ValueError("the wavelength grid drives the 4-wave model; six waves use fill_dbeta_pairs")
+        ax2, ax3 = self._axis("l2", lambda2_axis), self._axis("l3", lambda3_axis)
+        _native.dbeta_grid_device(model, lambda1_m, stream=self._stream(), d_lambda2_axis=ax2.data_ptr(), n2=ax2.numel(),
+                                  d_lambda3_axis=ax3.data_ptr(), n3=ax3.numel(), first=int(first), n_points=self.n_local,
+                                  d_dbeta=self.dbeta.data_ptr(), dtype=self.np_dtype)
+
+    def fill_dbeta_pairs(self, model: dict, omega_d: float, Omega1_axis, Omega2_axis, *, first: int) -> None:
+        """Six waves: (dbeta_1, dbeta_2) of this rank's block of the flattened Omega1 x Omega2 grid."""
+        if self.n_waves != 6:
+            raise ValueError("fill_dbeta_pairs is for the six-wave model")
+        ax1, ax2 = self._axis("O1", Omega1_axis), self._axis("O2", Omega2_axis)
+        _native.dbeta_pairs_device(model, omega_d, stream=self._stream(), d_Omega1_axis=ax1.data_ptr(), n1=ax1.numel(),
+                                   d_Omega2_axis=ax2.data_ptr(), n2=ax2.numel(), first=int(first), n_points=self.n_local,
+                                   d_dbeta1=self.dbeta.data_ptr(), d_dbeta2=self.dbeta2.data_ptr(), dtype=self.np_dtype)
+
+    # ---- the sweep ------------------------------------------------------------------------------------------------
     def launch(self) -> None:
         """Asynchronous: enqueue the sweep kernel on torch's current stream."""
-        r, n = self.record, self.n_local
-        es = r.element_size()
-        base = r.data_ptr()
-        _native.sweep_device(stream=torch.cuda.current_stream(self.device).cuda_stream, n_waves=4, n_points=n,
+        _native.sweep_device(stream=self._stream(), n_waves=self.n_waves, n_points=self.n_local,
                              n_steps=self.n_steps, z_max=self.z_max, save_every=self.save_every,
-                             d_dbeta=self.dbeta.data_ptr(), d_dbeta2=0, d_gamma=self.gamma.data_ptr(),
-                             d_alpha=self.alpha.data_ptr(), d_a0_soa=self.a0_soa.data_ptr(), flags=self.flags,
-                             d_a_end_soa=base, d_p_end=base + 8 * n * es, d_p_max=base + 9 * n * es,
-                             d_first_bad=base + 10 * n * es,
-                             d_traj_soa=(self.traj.data_ptr() if self.traj is not None else 0))
+                             d_dbeta=self.dbeta.data_ptr(), d_dbeta2=(self.dbeta2.data_ptr() if self.dbeta2 is not None else 0),
+                             d_gamma=self.gamma.data_ptr(), d_alpha=self.alpha.data_ptr(), d_a0_soa=self.a0_soa.data_ptr(),
+                             flags=self.flags, d_a_end_soa=self._part("a_end"), d_p_end=self._part("p_end"),
+                             d_p_max=self._part("p_max"), d_first_bad=self._part("first_bad"),
+                             d_traj_soa=(self.traj.data_ptr() if self.traj is not None else 0), dtype=self.np_dtype)
 
     def summarize(self, p0_sig: float, *, mode: str = "max", gain_db: bool = True) -> None:
         """Enqueue the gain reduction of the sweep drivers (scan_mismtach.py:376-389 + argmax) on the same stream:
         fills ``self.gain`` (n_local,), ``self.best`` = [best_index, n_finite] (int64) and ``self.best_gain`` (1,)."""
+        if mode not in ("end", "max"):
+            raise ValueError(f"Unknown gain_mode={mode!r}. Use 'end' or 'max'.")
         if not hasattr(self, "gain"):
-            f64 = dict(dtype=torch.float64, device=self.device)
-            self.gain = torch.empty(self.n_local, **f64)
+            self.gain = torch.empty(self.n_local, dtype=self.tdtype, device=self.device)
             self.best = torch.zeros(2, dtype=torch.int64, device=self.device)
-            self.best_gain = torch.zeros(1, **f64)
+            self.best_gain = torch.zeros(1, dtype=torch.float64, device=self.device)
             self._ws = torch.empty(_native.gain_summary_workspace_bytes(self.n_local), dtype=torch.uint8, device=self.device)
-        es, n, base = self.record.element_size(), self.n_local, self.record.data_ptr()
-        row = 9 if mode == "max" else 8                      # p_sig_max | p_sig_end row of the record
-        _native.gain_summary_device(stream=torch.cuda.current_stream(self.device).cuda_stream, n_points=n,
-                                    d_p_metric=base + row * n * es, d_first_bad=base + 10 * n * es, p0_sig=p0_sig,
-                                    gain_db=gain_db, d_gain=self.gain.data_ptr(), d_best_index=self.best.data_ptr(),
+        _native.gain_summary_device(stream=self._stream(), n_points=self.n_local,
+                                    d_p_metric=self._part("p_max" if mode == "max" else "p_end"),
+                                    d_first_bad=self._part("first_bad"), p0_sig=p0_sig, gain_db=gain_db,
+                                    d_gain=self.gain.data_ptr(), d_best_index=self.best.data_ptr(),
                                     d_best_gain=self.best_gain.data_ptr(), d_n_finite=self.best.data_ptr() + 8,
-                                    d_workspace=self._ws.data_ptr())
+                                    d_workspace=self._ws.data_ptr(), dtype=self.np_dtype)
 
     def enable_trajectory(self) -> int:
         """Allocate the trajectory buffer [n_saved][n_waves][n_local][2] ((re, im) pairs) in HBM; returns its bytes."""
         n_saved = self.n_steps // self.save_every + 1
-        self.traj = torch.empty((n_saved, self.n_waves, self.n_local, 2), dtype=torch.float64, device=self.device)
+        self.traj = torch.empty((n_saved, self.n_waves, self.n_local, 2), dtype=self.tdtype, device=self.device)
         return self.traj.numel() * self.traj.element_size()
 
     def gather(self, group=None) -> torch.Tensor:
-        """One all_gather of the record over the process group -> (world, rows, n_local) on this GPU."""
+        """One all_gather of the record over the process group -> (world, words(pad_to)) int64 on this GPU.  Every rank
+        must have been built with the same ``pad_to`` (the widest block); trim with ``unpack_gathered``."""
         world = dist.get_world_size(group)
-        out = torch.empty(world * self.record.numel(), dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(out, self.record.reshape(-1).view(torch.int64), group=group)   # bit copy
-        return out.view(torch.float64).reshape((world,) + tuple(self.record.shape))
+        with torch.cuda.device(self.device):
+            return _all_gather_words(self.record, world, group)
 
     def result(self) -> SweepResult:
-        rec = self.record.cpu().numpy()
-        a, pe, pm, fb = unpack_records(rec[None], self.n_local, 1, 4)
+        a, pe, pm, fb = self.layout.unpack(self.record.cpu().numpy(), self.n_local)
         return SweepResult(a, pe, pm, fb, self.n_steps, self.save_every, 0.0)

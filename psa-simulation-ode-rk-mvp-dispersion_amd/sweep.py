@@ -54,8 +54,11 @@ class SweepResult:
         if u not in ("db", "linear"):
             raise ValueError("gain_unit must be 'dB' or 'linear'")
         metric = self.p_max if mode == "max" else self.p_end
-        return _native.gain_summary_host(np.asarray(metric, dtype=np.float64), self.first_bad_step, float(p0_sig),
-                                         gain_db=(u == "db"), device=device)
+        # a float32 sweep keeps float32 gains (psa_gain_summary_f32); everything else is reduced in float64
+        metric = np.asarray(metric)
+        if metric.dtype != np.float32:
+            metric = metric.astype(np.float64, copy=False)
+        return _native.gain_summary_host(metric, self.first_bad_step, float(p0_sig), gain_db=(u == "db"), device=device)
 
 
 def rk4_sweep(dbeta, *, z_max: float, dz: Optional[float] = None, n_steps: Optional[int] = None,

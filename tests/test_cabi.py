@@ -36,7 +36,8 @@ def test_flag_values_match_the_header():
                       ("PSA_BCAST_A0", nat.BCAST_A0), ("PSA_OPT_CHECK_NAN", nat.OPT_CHECK_NAN),
                       ("PSA_OPT_EXACT_STEP", nat.OPT_EXACT_STEP), ("PSA_OPT_LDS_STAGING", nat.OPT_LDS_STAGING),
                       ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64), ("PSA_OPT_F32_SCALAR", nat.OPT_F32_SCALAR),
-                      ("PSA_OPT_F32_PACKED", nat.OPT_F32_PACKED), ("PSA_OPT_LOSSLESS", nat.OPT_LOSSLESS)):
+                      ("PSA_OPT_F32_PACKED", nat.OPT_F32_PACKED), ("PSA_OPT_LOSSLESS", nat.OPT_LOSSLESS),
+                      ("PSA_OPT_SPLIT_POINT", nat.OPT_SPLIT_POINT), ("PSA_OPT_ONE_LANE", nat.OPT_ONE_LANE)):
         m = re.search(rf"#define\s+{name}\s+\(1u\s*<<\s*(\d+)\)", src)
         assert m and (1 << int(m.group(1))) == val, name
 
@@ -152,3 +153,59 @@ def test_header_is_valid_c99_and_a_c_program_links_and_gets_the_documented_codes
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "abi_client ok" in out.stdout
+
+
+def test_dbeta_producer_validates_its_model_before_any_launch():
+    """psa_dbeta_grid_*_dev / psa_dbeta_pairs_*_dev: bad method / orders / beta count / block -> negative codes, no launch."""
+    L = nat.lib()
+    buf = np.zeros(16)
+    p = buf.ctypes.data_as(C.c_void_p)
+    beta = np.zeros(9)
+    beta[2] = -1e-28
+    pb = beta.ctypes.data_as(C.c_void_p)
+    ok_orders = np.array([2, 4], np.int32)
+    po = ok_orders.ctypes.data_as(C.c_void_p)
+
+    def grid(method=0, orders=po, n_orders=2, max_order=4, n_beta=9, n2=2, n3=4, first=0, n=8, out=p):
+        return L.psa_dbeta_grid_f64_dev(None, method, orders, n_orders, max_order, pb, n_beta, 1.2e15, 1.88e9, 0.0, 1e-12,
+                                        1550e-9, p, n2, p, n3, first, n, out, None)
+
+    assert grid(method=7) == -10
+    assert grid(n_orders=0) == -10 and grid(n_orders=5) == -10 and grid(orders=None) == -10
+    odd = np.array([2, 3], np.int32)
+    assert grid(orders=odd.ctypes.data_as(C.c_void_p)) == -10
+    big = np.array([2, 10], np.int32)
+    assert grid(orders=big.ctypes.data_as(C.c_void_p)) == -10
+    assert grid(n_beta=0) == -10 and grid(n_beta=10) == -10
+    assert grid(method=1, max_order=9) == -10
+    assert grid(first=4, n=8) == -2           # block leaves the 2 x 4 grid
+    assert grid(n2=0) == -2 and grid(n=-1) == -2
+    assert grid(out=None) == -6
+    assert grid(n=0) == 0                       # empty block: a valid no-op, no device needed
+    assert len(L.psa_last_error()) > 0
+    assert L.psa_dbeta_pairs_f64_dev(None, po, 2, pb, 9, 1e12, p, 2, p, 2, 0, 5, p, p) == -2
+    assert L.psa_dbeta_pairs_f64_dev(None, po, 2, pb, 9, 1e12, p, 2, p, 2, 0, 0, None, None) == 0
+    assert L.psa_gain_summary_f32_dev(None, -1, p, None, 1.0, 1, p, p, p, p, p) == -2
+    assert L.psa_gain_summary_f32_dev(None, 4, None, None, 1.0, 1, p, p, p, p, p) == -6
+
+
+def test_n_points_beyond_the_launch_grid_is_too_large():
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    rc = nat.lib().psa_rk4_sweep_f64_dev(None, 4, 64 * (2**31 - 1) + 1, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, None)
+    assert rc == -9
+
+
+def test_dbeta_model_description_of_the_python_carriers():
+    from psa_amd import dispersion, phase_matching
+    d = dispersion.DispersionParams(omega_ref=1.2e15, beta2=-2e-28, beta3=4e-41, beta4=-3e-55, extra={6: 1e-84})
+    m = nat.dbeta_model(d, phase_matching.PhaseMatchingConfig(even_orders=(2, 4, 6)))
+    assert m["method"] == nat.DBETA_SYMMETRIC_EVEN and list(m["orders"]) == [2, 4, 6] and m["beta"][6] == 1e-84
+    m = nat.dbeta_model(d, phase_matching.PhaseMatchingConfig(method="general_taylor", max_order=6))
+    assert m["method"] == nat.DBETA_GENERAL_TAYLOR and m["max_order"] == 6
+    with pytest.raises(ValueError):
+        nat.dbeta_model(d, phase_matching.PhaseMatchingConfig(method="provided", provided_delta_beta=0.1))
+    with pytest.raises(ValueError):
+        nat.dbeta_model(dispersion.DispersionParams(omega_ref=1.2e15, extra={10: 1e-140}), phase_matching.PhaseMatchingConfig())
+    with pytest.raises(ValueError):
+        nat.dbeta_model(None, phase_matching.PhaseMatchingConfig())

@@ -189,7 +189,7 @@ def test_sharded_sweep_through_rccl_with_one_rank(oracle):
     import socket
     import torch
     import torch.distributed as dist
-    from psa_amd.distributed import DeviceSweep, sweep_sharded, unpack_records
+    from psa_amd.distributed import DeviceSweep, sweep_sharded, unpack_gathered
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -206,7 +206,7 @@ def test_sharded_sweep_through_rccl_with_one_rank(oracle):
         ds.launch()
         g = ds.gather()
         torch.cuda.synchronize()
-        a, pe, pm, fb = unpack_records(g.cpu().numpy(), db.size, 1, 4)
+        a, pe, pm, fb = unpack_gathered(ds.layout, g.cpu().numpy(), db.size, 1)
         assert np.array_equal(a, res.a_end) and np.array_equal(pm, res.p_max) and (fb == -1).all()
     finally:
         dist.destroy_process_group()
@@ -288,7 +288,7 @@ def test_device_entry_point_can_be_captured_into_a_graph_and_replayed(oracle):
     """include/psa_rk4.h: the `_dev` entry points neither allocate nor synchronise.  Capture one sweep launch into a
     HIP graph (through torch.cuda.CUDAGraph), change the inputs in place, replay, and compare with the oracle."""
     import torch
-    from psa_amd.distributed import DeviceSweep, unpack_records
+    from psa_amd.distributed import DeviceSweep
     a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
     db1 = np.linspace(-0.05, 0.05, 500)
     db2 = np.linspace(0.02, -0.03, 500)
@@ -306,7 +306,7 @@ def test_device_entry_point_can_be_captured_into_a_graph_and_replayed(oracle):
         ds.record.zero_()
         graph.replay()
         torch.cuda.synchronize()
-        a, pe, pm, fb = unpack_records(ds.record.cpu().numpy()[None], db.size, 1, 4)
+        a, pe, pm, fb = ds.layout.unpack(ds.record.cpu().numpy(), db.size)
         ref = oracle.sweep(db, z_max=80.0, n=800, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
         assert rel_err(a, ref["a_end"]) < RTOL_F64 and rel_err(pm, ref["p_max"]) < RTOL_F64 and (fb == -1).all()
 

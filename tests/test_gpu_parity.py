@@ -35,7 +35,8 @@ def test_sweep_matches_oracle_on_ragged_sizes(oracle, N, n, se):
     rng = np.random.default_rng(100 * N + n)
     db = rng.uniform(-0.1, 0.1, N)
     ref = oracle.sweep(db, z_max=100.0, n=n, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0)
-    for flags in (0, nat.OPT_BLOCK64):
+    # one lane per point (256- and 64-thread workgroups), two lanes per point, and the library's own choice
+    for flags in (nat.OPT_ONE_LANE, nat.OPT_ONE_LANE | nat.OPT_BLOCK64, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, 0):
         got = nat.sweep_host(db, n_steps=n, z_max=100.0, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0,
                              check_nan=True, exact_step=True, extra_flags=flags)
         assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
@@ -56,10 +57,11 @@ def test_per_point_gamma_alpha_a0_robustness_draw(oracle):
                   10 ** rng.uniform(-7, -4, N)], 1)
     a0 = np.sqrt(P) * np.exp(1j * rng.uniform(-np.pi, np.pi, (N, 4)))
     ref = oracle.sweep(db, z_max=400.0, n=4000, save_every=10, gamma=gamma, alpha=alpha, a0=a0)
-    got = nat.sweep_host(db, n_steps=4000, z_max=400.0, save_every=10, gamma=gamma, alpha=alpha, a0=a0)
-    assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
-    assert rel_err(got["p_max"], ref["p_max"]) < RTOL_F64
-    assert (got["first_bad_step"] == -1).all()
+    for lanes in (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT):
+        got = nat.sweep_host(db, n_steps=4000, z_max=400.0, save_every=10, gamma=gamma, alpha=alpha, a0=a0, extra_flags=lanes)
+        assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
+        assert rel_err(got["p_max"], ref["p_max"]) < RTOL_F64
+        assert (got["first_bad_step"] == -1).all()
     # broadcast flags one at a time
     for kw in (dict(gamma=0.0115), dict(alpha=1e-4), dict(a0=a0[3])):
         args = dict(gamma=gamma, alpha=alpha, a0=a0)
@@ -418,7 +420,8 @@ def test_config4_per_gpu_shard_at_full_length_float32(oracle):
 
 def test_randomized_differential_against_oracle(oracle):
     """60 seeded random configurations: point count, step count, save stride (below / at / above the 32-step chunk and
-    the 64-step re-seed period), check mode, trajectory on/off, 4 or 6 waves, broadcast or per-point gamma/alpha/A0."""
+    the 64-step re-seed period), check mode, trajectory on/off, 4 or 6 waves, broadcast or per-point gamma/alpha/A0,
+    one or two lanes per sweep point."""
     rng = np.random.default_rng(20261004)
     strides = [1, 2, 3, 7, 10, 31, 32, 33, 63, 64, 65, 100, 257, 1000]
     for case in range(60):
@@ -435,10 +438,11 @@ def test_randomized_differential_against_oracle(oracle):
         alpha = rng.uniform(0, 3e-4, N) if rng.integers(0, 2) else float(rng.choice([0.0, 1.15e-4]))
         amp = np.sqrt(rng.uniform(1e-6, 0.8, (N, nw))) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, nw)))
         a0 = amp if rng.integers(0, 2) else amp[0]
-        tag = f"case {case}: N={N} n={n} se={se} nw={nw} check={check} exact={exact} traj={traj}"
+        lanes = int(rng.choice([nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT]))
+        tag = f"case {case}: N={N} n={n} se={se} nw={nw} check={check} exact={exact} traj={traj} lanes={lanes:#x}"
         ref = oracle.sweep(db, z_max=L, n=n, save_every=se, check_nan=check, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2)
         got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2,
-                             check_nan=check, exact_step=exact, want_traj=traj)
+                             check_nan=check, exact_step=exact, want_traj=traj, extra_flags=lanes)
         assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64, tag
         assert rel_err(got["p_end"], ref["p_end"]) < RTOL_F64 and rel_err(got["p_max"], ref["p_max"]) < RTOL_F64, tag
         assert np.array_equal(got["first_bad_step"], ref["first_bad_step"]) and (got["first_bad_step"] == -1).all(), tag
@@ -470,13 +474,15 @@ def test_extreme_parameters(oracle):
     alpha = 10 ** rng.uniform(-6, -2, N)
     n, L = 50_000, 1000.0              # h = 0.02 m
     ref = oracle.sweep(db, z_max=L, n=n, save_every=100, gamma=gamma, alpha=alpha, a0=a0)
-    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=100, gamma=gamma, alpha=alpha, a0=a0, exact_step=True)
-    assert (got["first_bad_step"] == -1).all() and (ref["first_bad_step"] == -1).all()
-    scale = np.abs(ref["a_end"]).max(axis=1, keepdims=True)
-    # per-point normalisation: a wave that is ~1e-12 of the pumps carries absolute, not relative, rounding noise
-    assert np.max(np.abs(got["a_end"] - ref["a_end"]) / scale) < RTOL_F64
-    strong = np.abs(ref["a_end"]) > 1e-6 * scale
-    assert rel_err(got["a_end"][strong], ref["a_end"][strong]) < 1e-7
-    assert np.all(got["a_end"][0, 2:] == 0) and np.all(got["a_end"][1, :2] == 0)
-    live = ref["p_max"] > 0
-    assert rel_err(got["p_max"][live], ref["p_max"][live]) < 1e-7
+    for lanes in (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT):
+        got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=100, gamma=gamma, alpha=alpha, a0=a0, exact_step=True,
+                             extra_flags=lanes)
+        assert (got["first_bad_step"] == -1).all() and (ref["first_bad_step"] == -1).all()
+        scale = np.abs(ref["a_end"]).max(axis=1, keepdims=True)
+        # per-point normalisation: a wave that is ~1e-12 of the pumps carries absolute, not relative, rounding noise
+        assert np.max(np.abs(got["a_end"] - ref["a_end"]) / scale) < RTOL_F64
+        strong = np.abs(ref["a_end"]) > 1e-6 * scale
+        assert rel_err(got["a_end"][strong], ref["a_end"][strong]) < 1e-7
+        assert np.all(got["a_end"][0, 2:] == 0) and np.all(got["a_end"][1, :2] == 0)
+        live = ref["p_max"] > 0
+        assert rel_err(got["p_max"][live], ref["p_max"][live]) < 1e-7

@@ -1,0 +1,181 @@
+"""The HBM-resident shard object the multi-GPU path and bench.py are built on (``distributed.DeviceSweep``) for every
+configuration BASELINE.json shards: float64 / float32, four / six waves, dbeta from the host or generated on the GPU,
+device-side gain summary, and the RCCL leg (world_size 1 on this one-GPU box; world_size 2 and 3 run under gloo on
+CPU in tests/test_distributed_gloo.py).  Checker: the oracle; tolerances as tests/test_gpu_parity.py.
+"""
+import socket
+
+import numpy as np
+import pytest
+
+import psa_amd._native as nat
+from conftest import ATOL_DB, RTOL_F32, RTOL_F64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+P4 = np.array([0.5, 0.5, 1e-5, 1e-5])
+P6 = np.array([0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7])
+A4, A6 = np.sqrt(P4).astype(complex), np.sqrt(P6).astype(complex)
+
+
+@pytest.fixture(scope="module")
+def rccl_one_rank():
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_device_gain_summary_and_gather_on_a_sweep_with_failing_points(oracle, rccl_one_rank):
+    """scan_mismtach.py:376-392 on the device: per-point gain in dB, NaN for failed points, best index, n_finite -- for
+    1 500 points of which every 97th blows up (gamma past the RK4 stability edge) -- then the record through RCCL."""
+    import torch
+    from psa_amd.distributed import DeviceSweep, unpack_gathered
+    N = 1500
+    rng = np.random.default_rng(8)
+    db = rng.uniform(-0.05, 0.05, N)
+    ds = DeviceSweep(db, n_steps=1000, z_max=100.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A4, pad_to=N + 3)
+    # per-point gamma is not part of DeviceSweep's broadcast interface: swap in a per-point array and clear the flag
+    gam = np.full(N, 0.0115)
+    gam[::97] = 60.0
+    ds.gamma = torch.as_tensor(gam).to(ds.device)
+    ds.flags &= ~nat.BCAST_GAMMA
+    ref = oracle.sweep(db, z_max=100.0, n=1000, save_every=10, gamma=gam, alpha=1.15e-4, a0=A4)
+    for mode, key in (("max", "p_max"), ("end", "p_end")):
+        ds.launch()
+        ds.summarize(float(P4[2]), mode=mode, gain_db=True)
+        torch.cuda.synchronize()
+        want = oracle.gain_from_summary(ref[key], ref["first_bad_step"], P4[2], "db")
+        got = ds.gain.cpu().numpy()
+        failed = ref["first_bad_step"] >= 0
+        assert failed.sum() == len(range(0, N, 97)) and np.array_equal(np.isnan(got), failed)
+        assert np.max(np.abs(got[~failed] - want[~failed])) < ATOL_DB
+        best_i, n_fin = (int(v) for v in ds.best.cpu().numpy())
+        assert n_fin == int((~failed).sum())
+        assert best_i == int(np.nanargmax(want)) and abs(float(ds.best_gain.item()) - np.nanmax(want)) < ATOL_DB
+    ds.summarize(float(P4[2]), mode="max", gain_db=False)            # linear gain
+    torch.cuda.synchronize()
+    lin = ds.gain.cpu().numpy()
+    assert rel_err(lin[~failed], (ref["p_max"] / P4[2])[~failed]) < RTOL_F64
+    g = ds.gather()
+    torch.cuda.synchronize()
+    assert g.shape == (1, ds.layout.words(N + 3))                     # padded to the widest block of the (virtual) split
+    a, pe, pm, fb = unpack_gathered(ds.layout, g.cpu().numpy(), N, 1)
+    res = ds.result()
+    assert np.array_equal(a, res.a_end, equal_nan=True) and np.array_equal(fb, res.first_bad_step)
+    assert np.array_equal(fb >= 0, failed)
+    assert rel_err(a[~failed], ref["a_end"][~failed]) < RTOL_F64
+
+
+@pytest.mark.parametrize("N", [4096, 4097])
+def test_float32_shard_object(oracle, rccl_one_rank, N):
+    """BASELINE config 4's arithmetic: the packed float32 kernel writes straight into the float32 record (48 B/point);
+    gain summary through psa_gain_summary_f32_dev; odd N exercises the half-filled last lane."""
+    import torch
+    from psa_amd.distributed import DeviceSweep, unpack_gathered
+    db = np.linspace(-0.02, 0.02, N)
+    ds = DeviceSweep(db, n_steps=4000, z_max=400.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A4, dtype=np.float32)
+    assert ds.record.numel() * 8 == 48 * N
+    ds.launch()
+    ds.summarize(float(P4[2]), mode="max", gain_db=True)
+    g = ds.gather()
+    torch.cuda.synchronize()
+    ref = oracle.sweep(db.astype(np.float32).astype(np.float64), z_max=400.0, n=4000, save_every=10, gamma=0.0115,
+                       alpha=1.15e-4, a0=A4)
+    a, pe, pm, fb = unpack_gathered(ds.layout, g.cpu().numpy(), N, 1)
+    assert a.dtype == np.complex64 and pm.dtype == np.float32 and (fb == -1).all()
+    assert rel_err(a.astype(complex), ref["a_end"]) < RTOL_F32 and rel_err(pm.astype(float), ref["p_max"]) < RTOL_F32
+    want = oracle.gain_from_summary(ref["p_max"], ref["first_bad_step"], P4[2], "db")
+    got = ds.gain.cpu().numpy()
+    assert got.dtype == np.float32 and np.max(np.abs(got - want)) < 5e-4
+    best_i, n_fin = (int(v) for v in ds.best.cpu().numpy())
+    assert n_fin == N and abs(want[best_i] - want.max()) < 5e-4
+
+
+def test_six_wave_shard_object_with_device_generated_mismatch(oracle, rccl_one_rank):
+    """BASELINE config 5's shape in small: a block of the (Omega1 x Omega2) grid, (dbeta_1, dbeta_2) produced on the GPU
+    by psa_dbeta_pairs_f64_dev, six-wave float64 kernel, 120 B/point record."""
+    import torch
+    from psa_amd import dispersion, frequency_plan
+    from psa_amd.distributed import DeviceSweep, shard_bounds
+    d = dispersion.dispersion_params_from_D_S(1554e-9, 0.1, 0.02, 0.0, D_units="ps/nm/km", S_units="ps/nm^2/km",
+                                              dSdlmbd_units="ps/nm^3/km")
+    w1, w2 = frequency_plan.omega_from_lambda(1550e-9), frequency_plan.omega_from_lambda(1558e-9)
+    wd = 0.5 * (w1 - w2)
+    O1, O2 = np.linspace(2e12, 2.4e13, 24), np.linspace(3e12, 2.0e13, 31)
+    r1 = dispersion.delta_beta_symmetric_array(wd, O1, d)
+    r2 = dispersion.delta_beta_symmetric_array(wd, O2, d)
+    R1, R2 = (m.ravel() for m in np.meshgrid(r1, r2, indexing="ij"))
+    lo, hi = shard_bounds(O1.size * O2.size, 3, 1)                    # the middle one of three ragged blocks
+    ds = DeviceSweep(n_local=hi - lo, n_steps=3000, z_max=300.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6)
+    ds.fill_dbeta_pairs(nat.dbeta_model(d, None, even_orders=(2, 4)), wd, O1, O2, first=lo)
+    ds.launch()
+    ds.summarize(float(P6[2]), mode="max", gain_db=True)
+    torch.cuda.synchronize()
+    assert ds.record.numel() * 8 == 120 * (hi - lo)
+    np.testing.assert_allclose(ds.dbeta.cpu().numpy(), R1[lo:hi], rtol=3e-16)
+    np.testing.assert_allclose(ds.dbeta2.cpu().numpy(), R2[lo:hi], rtol=3e-16)
+    ref = oracle.sweep(R1[lo:hi], dbeta2=R2[lo:hi], z_max=300.0, n=3000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6)
+    res = ds.result()
+    assert res.a_end.shape == (hi - lo, 6)
+    assert rel_err(res.a_end, ref["a_end"]) < RTOL_F64 and rel_err(res.p_max, ref["p_max"]) < RTOL_F64
+    want = oracle.gain_from_summary(ref["p_max"], ref["first_bad_step"], P6[2], "db")
+    assert np.max(np.abs(ds.gain.cpu().numpy() - want)) < ATOL_DB
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_wavelength_grid_generated_per_block_equals_the_grid_driver(oracle, dtype):
+    """Config 3 / config 4 shape in small: every rank's block of the lambda_p2 x lambda_3 grid gets its dbeta from
+    psa_dbeta_grid_*_dev; the three blocks together must equal scan_gain_grid's host-generated run (gain and NaN mask:
+    the 0.7 um column has no idler, scan_mismtach.py:391-392)."""
+    import torch
+    from psa_amd import config, dispersion, scan_mismtach
+    from psa_amd.distributed import DeviceSweep, shard_bounds
+    from psa_amd.phase_matching import PhaseMatchingConfig
+    lam2 = np.linspace(1552e-9, 1562e-9, 9)
+    lam3 = np.concatenate([np.linspace(1540e-9, 1565e-9, 20), [0.7e-6]])
+    d = dispersion.dispersion_params_from_D_S(1554e-9, 0.1, 0.02, 0.0, D_units="ps/nm/km", S_units="ps/nm^2/km",
+                                              dSdlmbd_units="ps/nm^3/km")
+    p_in = np.array([0.1, 0.1, 1e-7, 1e-7])
+    cfg = config.custom_simulation_config(z_max=300.0, dz=0.1)
+    host = scan_mismtach.scan_gain_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=lam2, lambda_signal_m=lam3, gamma=0.0115,
+                                        alpha=1.15e-4, p_in=p_in, dispersion=d)
+    model = nat.dbeta_model(d, PhaseMatchingConfig())
+    N = lam2.size * lam3.size
+    gains = []
+    for r in range(3):
+        lo, hi = shard_bounds(N, 3, r)
+        ds = DeviceSweep(n_local=hi - lo, n_steps=3000, z_max=300.0, save_every=cfg.save_every, gamma=0.0115, alpha=1.15e-4,
+                         a0=np.sqrt(p_in).astype(complex), dtype=dtype)
+        ds.fill_dbeta_grid(model, 1550e-9, lam2, lam3, first=lo)
+        ds.launch()
+        ds.summarize(float(p_in[2]), mode="max", gain_db=True)
+        torch.cuda.synchronize()
+        gains.append(ds.gain.cpu().numpy().astype(np.float64))
+    gain = np.concatenate(gains).reshape(lam2.size, lam3.size)
+    assert np.array_equal(np.isnan(gain), np.isnan(host["gain"])) and np.isnan(gain[:, -1]).all()
+    live = ~np.isnan(gain)
+    tol = ATOL_DB if dtype == np.float64 else 2e-3
+    assert np.max(np.abs(gain[live] - host["gain"][live])) < tol
+
+
+def test_sweep_sharded_float32_and_six_waves_through_rccl(oracle, rccl_one_rank):
+    """distributed.sweep_sharded(dtype=float32) and the six-wave record over the nccl backend (one rank here)."""
+    from psa_amd.distributed import sweep_sharded
+    db = np.linspace(-0.03, 0.03, 501)
+    r32 = sweep_sharded(db, n_steps=2000, z_max=200.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A4, dtype=np.float32)
+    ref = oracle.sweep(db.astype(np.float32).astype(np.float64), z_max=200.0, n=2000, save_every=10, gamma=0.0115,
+                       alpha=1.15e-4, a0=A4)
+    assert r32.a_end.dtype == np.complex64 and rel_err(r32.a_end.astype(complex), ref["a_end"]) < RTOL_F32
+    g32 = r32.gain(P4[2], mode="max", unit="dB")
+    assert g32.dtype == np.float32
+    r6 = sweep_sharded(db, dbeta2=-0.4 * db, n_steps=2000, z_max=200.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6)
+    ref6 = oracle.sweep(db, dbeta2=-0.4 * db, z_max=200.0, n=2000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6)
+    assert r6.a_end.shape == (501, 6) and rel_err(r6.a_end, ref6["a_end"]) < RTOL_F64
+    assert np.array_equal(r6.first_bad_step, ref6["first_bad_step"])

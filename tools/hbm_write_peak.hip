@@ -1,0 +1,58 @@
+// Developer probe: the store-only ceiling of the trajectory layout on this GPU.  Every lane writes one 16-byte
+// (re, im) pair per wave per row into [row][wave][N] -- the same 1 KiB-per-wave-instruction stream the sweep kernel
+// emits in trajectory mode (save_every = 1) -- with no arithmetic in between.  Compares default, non-temporal and
+// "slc|glc"-style stores and different numbers of resident waves.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/hbm_write_peak.hip -o tools/hbm_write_peak ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__global__ void __launch_bounds__(256) rows_kernel(d2 *traj, long long n, int rows, int spin) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    double x = (double)idx * 1e-9, y = 1.0;
+    for (int r = 0; r < rows; ++r) {
+        for (int k = 0; k < spin; ++k) {  // stand-in for the FP64 work of a step (dependent chain)
+            x = __builtin_fma(x, 1.0000001, 1e-9);
+            y = __builtin_fma(y, 0.9999999, x);
+        }
+        d2 *dst = traj + (long long)r * 4 * n + idx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const d2 v = {x + j, y};
+            if (NT) __builtin_nontemporal_store(v, dst + (long long)j * n);
+            else dst[(long long)j * n] = v;
+        }
+    }
+}
+
+int main() {
+    const long long n = 262144;
+    const int rows = 401;
+    d2 *buf;
+    const size_t bytes = (size_t)rows * 4 * n * sizeof(d2);
+    if (hipMalloc(&buf, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int nt = 0; nt < 2; ++nt)
+        for (int spin : {0, 16, 64, 150}) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipEventRecord(e0);
+                if (nt) hipLaunchKernelGGL(rows_kernel<true>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                else hipLaunchKernelGGL(rows_kernel<false>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("%s stores, %d dependent FMA pairs per row: %.3f ms -> %.0f GB/s (%.2f GB)\n", nt ? "non-temporal" : "default",
+                   spin, best, bytes / best / 1e6, bytes / 1e9);
+        }
+    hipFree(buf);
+    return 0;
+}

@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- RK4 field-point updates/s of the HIP sweep on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One bench "step" = one pass of the hot path over one batch: BASELINE config 2 per GPU -- 65 536 dbeta sweep
-points x 4 fields x 100 000 z-steps, float64, dbeta = linspace(-0.05, 0.05), gamma = 0.0115, alpha = 1.15e-4,
-P = (0.5, 0.5, 1e-5, 1e-5) W, L = 1000 m, save_every = 10, check_nan on (SURVEY 8d "C2").  Inputs are resident in
-HBM before the timed region; a step is the sweep kernel on the rank's shard, the on-device gain reduction (per-point gain
-+ argmax, the sweep drivers' summary) and, for N > 1, the single RCCL all_gather of the 88 B/point output record.  Weak scaling: every rank owns 65 536 points (rank r gets the r-th
-contiguous block of the global linspace).
+One bench "step" = one pass of the hot path over one batch.  The default workload (the headline, `--config c2`) is
+BASELINE config 2 per GPU: 65 536 dbeta sweep points x 4 fields x 100 000 z-steps, float64, dbeta = linspace(-0.05, 0.05),
+gamma = 0.0115, alpha = 1.15e-4, P = (0.5, 0.5, 1e-5, 1e-5) W, L = 1000 m, save_every = 10, check_nan on (SURVEY 8d "C2").
+The other BASELINE configurations run through the same code path:
+    c3  1 048 576 points per GPU (lambda_p2[1024] x lambda_3[1024] grid), 4 fields, 100 000 z-steps, float64
+    c4  131 072 points per GPU (one eighth of the 1024 x 1024 grid), 4 fields, 1 000 000 z-steps, float32
+    c5  32 768 points per GPU (one eighth of the 512 x 512 (Omega1, Omega2) grid), 6 fields, 100 000 z-steps, float64
+For c3-c5 every rank GENERATES the dbeta of its block on its own GPU (psa_dbeta_grid_*_dev / psa_dbeta_pairs_*_dev): no
+per-point input is scattered.  Inputs are resident in HBM before the timed region; a step is the sweep kernel on the
+rank's shard, the on-device gain reduction (per-point gain + argmax, the sweep drivers' summary) and, for N > 1, the single
+RCCL all_gather of the output record.  Weak scaling: every rank owns the same number of points (rank r gets the r-th
+contiguous block of a sweep that is N times as large); at N = 8 c4 and c5 are exactly BASELINE configs 4 and 5.
 
 Prints ONE JSON line on rank 0 (metric/value/unit/... + "roofline" + "cpu_baseline").
 """
@@ -32,83 +38,164 @@ import torch.distributed as dist  # noqa: E402
 import psa_amd._native as nat  # noqa: E402
 from psa_amd.distributed import DeviceSweep, shard_bounds  # noqa: E402
 
-# ---- workload: BASELINE.json configs[1] ------------------------------------------------------------------------
-PTS_PER_GPU = 65_536
-N_FIELDS = 4
-N_ZSTEPS = 100_000
 Z_MAX = 1000.0
 SAVE_EVERY = 10
 GAMMA, ALPHA = 0.0115, 1.15e-4
-P_IN = np.array([0.5, 0.5, 1e-5, 1e-5])
+P_C2 = np.array([0.5, 0.5, 1e-5, 1e-5])
+P_GRID = np.array([0.1, 0.1, 1e-7, 1e-7])
+P_SIX = np.array([0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7])
 DBETA_RANGE = (-0.05, 0.05)
 
-# ---- accounting agreed in BASELINE.md section 2 / SURVEY 8(d) ---------------------------------------------------
-FLOPS_PER_RK4_STEP = 652          # FP64 flops per sweep point per z-step (4-wave), + 2 sincos not counted
-BYTES_PER_POINT = 96              # dbeta in (8) + A_end (64) + p_end (8) + p_max (8) + first_bad_step (8)
-PEAK_FP64_VALU_TFLOPS = 78.6      # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (MI355X vector FP64)
-PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# ---- accounting agreed in BASELINE.md section 2 / SURVEY 8(d); the 6-wave count follows the same rules --
+FLOPS_PER_RK4_STEP = {4: 652, 6: 1156}      # real flops per sweep point per z-step, + 2 (4) sincos not counted
+PEAK_TFLOPS = {"f64": 78.6,                  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (vector FP64)
+               "f32": 157.3}                 # the same with two packed float32 per lane (v_pk_fma_f32)
+PEAK_HBM_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+CONFIGS = {
+    "c2": dict(baseline="configs[1]", n_waves=4, dtype="f64", pts_per_gpu=65_536, n_steps=100_000, p_in=P_C2,
+               what="65536 dbeta sweep points x 4 fields x 100000 z-steps, float64, per GPU (C2 inputs of SURVEY 8d)"),
+    "c3": dict(baseline="configs[2]", n_waves=4, dtype="f64", pts_per_gpu=1_048_576, n_steps=100_000, p_in=P_GRID, cols=1024,
+               what="1048576 sweep points (lambda_p2 x lambda_signal grid, 1024 columns) x 4 fields x 100000 z-steps, "
+                    "float64, per GPU; dbeta generated on the device"),
+    "c4": dict(baseline="configs[3]", n_waves=4, dtype="f32", pts_per_gpu=131_072, n_steps=1_000_000, p_in=P_GRID, cols=1024,
+               what="131072 sweep points per GPU (1/8 of the 1024 x 1024 grid) x 4 fields x 1000000 z-steps, float32; "
+                    "dbeta generated on the device"),
+    "c5": dict(baseline="configs[4]", n_waves=6, dtype="f64", pts_per_gpu=32_768, n_steps=100_000, p_in=P_SIX, cols=512,
+               what="6-wave RHS, 32768 sweep points per GPU (1/8 of the 512 x 512 (Omega1, Omega2) grid) x 6 fields x "
+                    "100000 z-steps, float64; dbeta_1, dbeta_2 generated on the device"),
+}
 
 
-def cpu_baseline(target_seconds: float = 6.0) -> dict:
+def grid_dispersion():
+    """Dispersion of the grid workloads (D = 0.1 ps/nm/km, S = 0.02 ps/nm^2/km at the G2 plan's centre)."""
+    from psa_amd import dispersion, frequency_plan
+    om = frequency_plan.plan_from_wavelengths(1550e-9, 1558e-9, 1540e-9)
+    sp = frequency_plan.infer_symmetry_from_omegas(*om)
+    return dispersion.dispersion_params_from_D_S(frequency_plan.lambda_from_omega(sp.omega_c), 0.1, 0.02, 0,
+                                                 D_units="ps/nm/km", S_units="ps/nm^2/km", dSdlmbd_units="ps/nm^3/km",
+                                                 omega_ref=sp.omega_c)
+
+
+def build_shard(name: str, world: int, rank: int, dev, extra_flags: int = 0, exact_step: bool = False):
+    """-> (DeviceSweep of this rank's block, n_global, host_dbeta(pick) -> (dbeta, dbeta2|None) for the parity guard)."""
+    from psa_amd import dispersion, frequency_plan
+    from psa_amd.phase_matching import PhaseMatchingConfig
+    c = CONFIGS[name]
+    n_global = c["pts_per_gpu"] * world
+    lo, hi = shard_bounds(n_global, world, rank)
+    np_dtype = np.float64 if c["dtype"] == "f64" else np.float32
+    kw = dict(n_steps=c["n_steps"], z_max=Z_MAX, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA,
+              a0=np.sqrt(c["p_in"]).astype(complex), dtype=np_dtype, check_nan=True, exact_step=exact_step, device=dev,
+              extra_flags=extra_flags, pad_to=c["pts_per_gpu"])
+    if name == "c2":
+        full = np.linspace(*DBETA_RANGE, n_global)
+        sweep = DeviceSweep(full[lo:hi], **kw)
+        return sweep, n_global, lambda pick: (full[lo:hi][pick], None)
+    d = grid_dispersion()
+    rows = n_global // c["cols"]
+    if c["n_waves"] == 4:
+        lam2, lam3 = np.linspace(1552e-9, 1562e-9, rows), np.linspace(1540e-9, 1565e-9, c["cols"])
+        sweep = DeviceSweep(n_local=hi - lo, **kw)
+        sweep.fill_dbeta_grid(nat.dbeta_model(d, PhaseMatchingConfig()), 1550e-9, lam2, lam3, first=lo)
+
+        def host_dbeta(pick):
+            from psa_amd.phase_matching import compute_phase_mismatch_batch
+            i = lo + np.asarray(pick)
+            om, ok = frequency_plan.plan_from_wavelengths_batch(1550e-9, lam2[i // c["cols"]], lam3[i % c["cols"]])
+            db, ok2 = compute_phase_mismatch_batch(om, d, PhaseMatchingConfig())
+            assert ok.all() and ok2.all()
+            return db, None
+        return sweep, n_global, host_dbeta
+    w1, w2 = frequency_plan.omega_from_lambda(1550e-9), frequency_plan.omega_from_lambda(1558e-9)
+    wd = 0.5 * (w1 - w2)
+    O1, O2 = np.linspace(2e12, 2.4e13, rows), np.linspace(3e12, 2.0e13, c["cols"])
+    sweep = DeviceSweep(n_local=hi - lo, **kw)
+    sweep.fill_dbeta_pairs(nat.dbeta_model(d, None, even_orders=(2, 4)), wd, O1, O2, first=lo)
+
+    def host_pairs(pick):
+        i = lo + np.asarray(pick)
+        return (dispersion.delta_beta_symmetric_array(wd, O1[i // c["cols"]], d),
+                dispersion.delta_beta_symmetric_array(wd, O2[i % c["cols"]], d))
+    return sweep, n_global, host_pairs
+
+
+def cpu_baseline(name: str, target_seconds: float = 6.0) -> dict:
     """CPU legs, all on a bounded sample of the SAME workload (called BEFORE the GPU is initialised):
-      * value: the oracle's C port (OpenMP over points, all host cores), P points x 100 000 steps with P sized from a
-        probe so it takes ~target_seconds of wall time (= target_seconds x cores of CPU work);
-      * the structurally faithful NumPy per-point restatement (the reference's own loop shape) on 1 core and on every
-        core (one process per core, forked before any OpenMP thread exists), and a batched-NumPy form, for context
+      * value: the oracle's C port (OpenMP over points, all host cores), P points at the configuration's full step count
+        with P sized from a probe so it takes ~target_seconds of wall time (float64 arithmetic also for c4);
+      * c2 only: the structurally faithful NumPy per-point restatement (the reference's own loop shape) on 1 core and on
+        every core (one process per core, forked before any OpenMP thread exists), and a batched-NumPy form, for context
         (SURVEY 8(d)(ii))."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    a0 = np.sqrt(P_IN).astype(complex)
+    c = CONFIGS[name]
+    nw, n_z = c["n_waves"], c["n_steps"]
+    a0 = np.sqrt(c["p_in"]).astype(complex)
     O.lib()
     # a one-GPU box's CPU share is 16 cores (more hardware threads may be visible); PSA_BENCH_CPU_CORES overrides
     cores = max(1, min(O.max_threads(), len(os.sched_getaffinity(0)), int(os.environ.get("PSA_BENCH_CPU_CORES", "16"))))
-    np_steps = N_ZSTEPS // 50
-    t = time.perf_counter()
-    O.np_integrate(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / N_ZSTEPS, save_every=SAVE_EVERY, check_nan=True, gamma=GAMMA,
-                   alpha=ALPHA, dbeta=0.01)
-    np_wall = time.perf_counter() - t
-    t = time.perf_counter()
-    O.np_integrate_all_cores(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / N_ZSTEPS, dbetas=np.linspace(*DBETA_RANGE, cores), procs=cores)
-    np_all_wall = time.perf_counter() - t
-    nb_pts, nb_steps = 4096, 100
-    t = time.perf_counter()
-    O.np_sweep_batched(np.linspace(*DBETA_RANGE, nb_pts), z_max=Z_MAX * nb_steps / N_ZSTEPS, n=nb_steps, gamma=GAMMA,
-                       alpha=ALPHA, a0=a0)
-    nb_wall = time.perf_counter() - t
+    extra = {}
+    if name == "c2":
+        np_steps = n_z // 50
+        t = time.perf_counter()
+        O.np_integrate(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / n_z, save_every=SAVE_EVERY, check_nan=True, gamma=GAMMA,
+                       alpha=ALPHA, dbeta=0.01)
+        np_wall = time.perf_counter() - t
+        t = time.perf_counter()
+        O.np_integrate_all_cores(a0, z_max=Z_MAX * 0.02, dz=Z_MAX / n_z, dbetas=np.linspace(*DBETA_RANGE, cores), procs=cores)
+        np_all_wall = time.perf_counter() - t
+        nb_pts, nb_steps = 4096, 100
+        t = time.perf_counter()
+        O.np_sweep_batched(np.linspace(*DBETA_RANGE, nb_pts), z_max=Z_MAX * nb_steps / n_z, n=nb_steps, gamma=GAMMA,
+                           alpha=ALPHA, a0=a0)
+        nb_wall = time.perf_counter() - t
+        extra = {"numpy_restatement_1core": {"value": nw * np_steps / np_wall,
+                                             "sample": f"1 point x {np_steps} z-steps, oracle.np_integrate "
+                                                       "(reference-shaped Python loop), 1 core"},
+                 "numpy_restatement_all_cores": {"value": cores * nw * np_steps / np_all_wall, "cores": cores,
+                                                 "sample": f"{cores} points x {np_steps} z-steps, one process per core "
+                                                           "(multiprocessing.Pool, pool start-up included)"},
+                 "numpy_batched_1core": {"value": nb_pts * nw * nb_steps / nb_wall,
+                                         "sample": f"{nb_pts} points x {nb_steps} z-steps, oracle.np_sweep_batched "
+                                                   "(arrays over sweep points)"}}
+
+    def run(pts):
+        db = np.linspace(*DBETA_RANGE, pts)
+        d2 = {"dbeta2": 0.5 * db[::-1]} if nw == 6 else {}
+        t0 = time.perf_counter()
+        O.sweep(db, z_max=Z_MAX, n=n_z, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores, **d2)
+        return time.perf_counter() - t0
+
     # the C port last: OpenMP worker threads appear only now
-    O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)  # warm
-    probe_pts = 4 * cores
-    t = time.perf_counter()
-    O.sweep(np.linspace(*DBETA_RANGE, probe_pts), z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA,
-            alpha=ALPHA, a0=a0, threads=cores)
-    probe = time.perf_counter() - t                               # four points per core at full length
+    O.sweep(np.zeros(cores), z_max=1.0, n=100, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores,
+            **({"dbeta2": np.zeros(cores)} if nw == 6 else {}))  # warm
+    probe_pts = cores
+    probe = run(probe_pts)                                        # one point per core at full length
     pts = max(cores, min(1 << 16, int(probe_pts * max(1.0, target_seconds / max(probe, 1e-3)))))
-    db = np.linspace(*DBETA_RANGE, pts)
-    t = time.perf_counter()
-    O.sweep(db, z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA, a0=a0, threads=cores)
-    wall = time.perf_counter() - t
-    return {"value": pts * N_FIELDS * N_ZSTEPS / wall, "unit": "field-point updates/s", "cores": cores, "kind": "port",
-            "sample": f"{pts} sweep points x {N_FIELDS} fields x {N_ZSTEPS} z-steps of the bench workload, "
-                      f"oracle/psa_oracle.c (scalar C99, OpenMP over points), {wall:.1f} s wall",
-            "numpy_restatement_1core": {"value": N_FIELDS * np_steps / np_wall,
-                                        "sample": f"1 point x {np_steps} z-steps, oracle.np_integrate "
-                                                  "(reference-shaped Python loop), 1 core"},
-            "numpy_restatement_all_cores": {"value": cores * N_FIELDS * np_steps / np_all_wall, "cores": cores,
-                                            "sample": f"{cores} points x {np_steps} z-steps, one process per core "
-                                                      "(multiprocessing.Pool, pool start-up included)"},
-            "numpy_batched_1core": {"value": nb_pts * N_FIELDS * nb_steps / nb_wall,
-                                    "sample": f"{nb_pts} points x {nb_steps} z-steps, oracle.np_sweep_batched "
-                                              "(arrays over sweep points)"}}
+    wall = run(pts) if pts > probe_pts else probe
+    out = {"value": pts * nw * n_z / wall, "unit": "field-point updates/s", "cores": cores, "kind": "port",
+           "sample": f"{pts} sweep points x {nw} fields x {n_z} z-steps of the bench workload, "
+                     f"oracle/psa_oracle.c (scalar C99 float64, OpenMP over points), {wall:.1f} s wall"}
+    out.update(extra)
+    return out
 
 
-def measured_traffic() -> dict | None:
-    """HBM bytes per launch from rocprofv3 PMC passes, if a summary has been committed under profiles/."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def profile_facts() -> dict:
+    """What the committed rocprofv3 runs measured for each configuration's dominant kernel (profiles/kernels.json, written
+    by tools/profile_summary.py): kernel symbol, VALU instructions per wave-step, HBM bytes per launch."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", "kernels.json")) as f:
             return json.load(f)
     except Exception:
-        return None
+        return {}
+
+
+def emit(out: dict, saved_stdout_fd: int) -> None:
+    sys.stdout.flush()
+    os.dup2(saved_stdout_fd, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
 
 
 def trajectory_mode(args, dev, saved_stdout_fd) -> None:
@@ -116,7 +203,7 @@ def trajectory_mode(args, dev, saved_stdout_fd) -> None:
     regime where this path is HBM-bound (64 B per point per step, ~10 flop/B).  Single GPU."""
     pts, nz = 262_144, 400
     sweep = DeviceSweep(np.linspace(*DBETA_RANGE, pts), n_steps=nz, z_max=nz * 0.01, save_every=1, gamma=GAMMA,
-                        alpha=ALPHA, a0=np.sqrt(P_IN).astype(complex), check_nan=True, device=dev)
+                        alpha=ALPHA, a0=np.sqrt(P_C2).astype(complex), check_nan=True, device=dev)
     traj_bytes = sweep.enable_trajectory()
     for _ in range(args.warmup):
         sweep.launch()
@@ -136,31 +223,31 @@ def trajectory_mode(args, dev, saved_stdout_fd) -> None:
     tr = sweep.traj[:, :, [0, pts // 2, pts - 1], :].cpu().numpy()       # [rows][4][3][2]
     err = 0.0
     for j, p in enumerate((0, pts // 2, pts - 1)):
-        z, A, _ = O.integrate(np.sqrt(P_IN).astype(complex), z_max=nz * 0.01, n=nz, save_every=1, gamma=GAMMA, alpha=ALPHA,
+        z, A, _ = O.integrate(np.sqrt(P_C2).astype(complex), z_max=nz * 0.01, n=nz, save_every=1, gamma=GAMMA, alpha=ALPHA,
                               dbeta=float(np.linspace(*DBETA_RANGE, pts)[p]))
         got = tr[:, :, j, 0] + 1j * tr[:, :, j, 1]
         err = max(err, float(np.max(np.abs(got - A) / np.abs(A))))
     if not err < 1e-9:
         raise SystemExit(f"trajectory bench failed its parity guard: {err}")
-    alg_bytes = traj_bytes + BYTES_PER_POINT * pts
+    facts = profile_facts().get("trajectory", {})
+    alg_bytes = traj_bytes + 96 * pts
     gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
     out = {"metric": "RK4 field-point updates/sec (sweep_pts x n_fields x n_zsteps / wall_s)",
-           "value": pts * N_FIELDS * nz * args.steps / wall, "unit": "field-point updates/s", "n_gpus": 1,
+           "value": pts * 4 * nz * args.steps / wall, "unit": "field-point updates/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "trajectory mode (NOT the headline config): 262144 sweep points x 4 fields x 400 z-steps, "
                                   "float64, every step saved to HBM (save_every = 1)", "sweep_pts": pts, "n_zsteps": nz,
                       "save_every": 1},
-           "roofline": {"kernel": "psa::rk4_sweep_kernel<double, 4, CHECK_BLOCK, true, 256>", "bound": "hbm",
-                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": kern_ms, "traffic": None,
-                        "note": "64 B per point per saved row, coalesced 512-B wave stores; the guide's measured "
-                                "achievable HBM rate is 6.3 TB/s"},
+           "roofline": {"kernel": facts.get("kernel", "psa::rk4_sweep_kernel<double, 4, 1, true, 256, false, true>"),
+                        "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": kern_ms,
+                        "traffic": facts.get("hbm_bytes_per_launch"), "traffic_source": facts.get("source"),
+                        "store_only_ceiling_gbs": facts.get("store_only_ceiling_gbs"),
+                        "note": "64 B per point per saved row, coalesced 1-KiB wave stores; a kernel that does nothing but "
+                                "these stores reaches store_only_ceiling_gbs on this chip (tools/hbm_write_peak.hip)"},
            "verify": {"trajectories_checked_vs_oracle": 3, "max_rel_err": err}}
-    sys.stdout.flush()
-    os.dup2(saved_stdout_fd, 1)
-    print(json.dumps(out), flush=True)
-    os.dup2(2, 1)
+    emit(out, saved_stdout_fd)
 
 
 def main() -> None:
@@ -168,14 +255,19 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE configuration per GPU (default c2 = the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the ~15 s CPU leg (profiling runs)")
     ap.add_argument("--block64", action="store_true", help="64-thread workgroups")
+    ap.add_argument("--one-lane", action="store_true", help="float64: never split a point over two lanes (A/B for c5)")
     ap.add_argument("--mode", choices=["summary", "trajectory"], default="summary",
                     help="summary (default): the BASELINE workload.  trajectory: the path's HBM-bound regime -- every "
                          "step saved (save_every = 1), 262 144 points x 400 z-steps, 6.7 GB of rows per launch; reports "
                          "an HBM roofline object.  Not the headline metric.")
     ap.add_argument("--exact-step", action="store_true", help="per-step finite test instead of per save block")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    nw, n_z, pts = cfg["n_waves"], cfg["n_steps"], cfg["pts_per_gpu"]
 
     # Exactly ONE line may reach stdout (the JSON, from rank 0).  RCCL prints a version banner with printf at
     # communicator creation, so fd 1 is pointed at stderr for the run and restored only for the final print.
@@ -190,10 +282,11 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # CPU legs first: they fork worker processes, which must happen before this process touches the GPU
+    # CPU legs first: one of them forks worker processes, which must happen before this process initialises the GPU
+    # runtime -- so the GPU is detected from the device node, not through torch / HIP
     cpu_leg = None
-    if world == 1 and args.mode == "summary" and not args.no_cpu_baseline and torch.cuda.device_count() > 0:
-        cpu_leg = cpu_baseline()
+    if world == 1 and args.mode == "summary" and not args.no_cpu_baseline and os.path.exists("/dev/kfd"):
+        cpu_leg = cpu_baseline(args.config)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -210,12 +303,9 @@ def main() -> None:
         return trajectory_mode(args, dev, saved_stdout_fd)
 
     # -- synthetic inputs of the workload, resident in HBM (rank's contiguous block of the global sweep)
-    n_global = PTS_PER_GPU * world
-    lo, hi = shard_bounds(n_global, world, rank)
-    dbeta = np.linspace(*DBETA_RANGE, n_global)[lo:hi]
-    sweep = DeviceSweep(dbeta, n_steps=N_ZSTEPS, z_max=Z_MAX, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA,
-                        a0=np.sqrt(P_IN).astype(complex), check_nan=True, exact_step=args.exact_step, device=dev,
-                        extra_flags=(nat.OPT_BLOCK64 if args.block64 else 0))
+    flags = (nat.OPT_BLOCK64 if args.block64 else 0) | (nat.OPT_ONE_LANE if args.one_lane else 0)
+    sweep, n_global, host_dbeta = build_shard(args.config, world, rank, dev, extra_flags=flags, exact_step=args.exact_step)
+    p0_sig = float(cfg["p_in"][2])
 
     def one_step(ev0=None, ev1=None):
         if ev0 is not None:
@@ -223,7 +313,7 @@ def main() -> None:
         sweep.launch()
         if ev1 is not None:
             ev1.record()
-        sweep.summarize(float(P_IN[2]), mode="max", gain_db=True)   # the drivers' per-point gain + argmax, on device
+        sweep.summarize(p0_sig, mode="max", gain_db=True)   # the drivers' per-point gain + argmax, on device
         return sweep.gather() if use_dist else None
 
     for _ in range(args.warmup):
@@ -251,62 +341,72 @@ def main() -> None:
     # -- post-run guard (not timed): the numbers just produced are the right numbers
     res = sweep.result()
     if use_dist:
-        assert gathered is not None and torch.equal(gathered[rank].view(torch.int64), sweep.record.view(torch.int64))
+        assert gathered is not None and torch.equal(gathered[rank], sweep.record)
     verify = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
-        pick = np.array([0, PTS_PER_GPU // 3, PTS_PER_GPU // 2, PTS_PER_GPU - 1])
-        ref = O.sweep(dbeta[pick], z_max=Z_MAX, n=N_ZSTEPS, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA,
-                      a0=np.sqrt(P_IN).astype(complex), threads=4)
-        err = float(np.max(np.abs(res.a_end[pick] - ref["a_end"]) / np.abs(ref["a_end"])))
-        gain_dev = sweep.gain.cpu().numpy()
-        gain_ref = O.gain_from_summary(ref["p_max"], ref["first_bad_step"], P_IN[2], "db")
+        f32 = cfg["dtype"] == "f32"
+        pick = np.array([0, pts // 3, pts // 2, pts - 1])
+        db_host, db2_host = host_dbeta(pick)
+        db_dev = sweep.dbeta.cpu().numpy()[pick].astype(np.float64)
+        err_db = float(np.max(np.abs(db_dev - db_host) / np.abs(db_host)))      # device-generated vs host producer
+        ref = O.sweep(db_dev, z_max=Z_MAX, n=n_z, save_every=SAVE_EVERY, gamma=GAMMA, alpha=ALPHA,
+                      a0=np.sqrt(cfg["p_in"]).astype(complex), threads=4,
+                      **({"dbeta2": sweep.dbeta2.cpu().numpy()[pick].astype(np.float64)} if nw == 6 else {}))
+        err = float(np.max(np.abs(res.a_end[pick].astype(complex) - ref["a_end"]) / np.abs(ref["a_end"])))
+        gain_dev = sweep.gain.cpu().numpy().astype(np.float64)
+        gain_ref = O.gain_from_summary(ref["p_max"], ref["first_bad_step"], p0_sig, "db")
         best_i, n_fin = (int(v) for v in sweep.best.cpu().numpy())
         err_gain = float(np.max(np.abs(gain_dev[pick] - gain_ref)))
         verify = {"points_checked_vs_oracle": int(pick.size), "max_rel_err_a_end": err, "max_err_gain_db": err_gain,
+                  "max_rel_err_dbeta_device_vs_host": err_db,
                   "all_finite": bool((res.first_bad_step == -1).all()), "best_gain_db": float(sweep.best_gain.item()),
                   "best_index": best_i}
-        if not (err < 1e-9 and err_gain < 5e-9 and verify["all_finite"] and n_fin == PTS_PER_GPU
-                and best_i == int(np.argmax(gain_dev))):
+        tol_a, tol_g, tol_db = (1e-4, 5e-4, 1e-7) if f32 else (1e-9, 5e-9, 4e-16)
+        if not (err < tol_a and err_gain < tol_g and err_db <= tol_db and verify["all_finite"] and n_fin == pts
+                and abs(gain_dev[best_i] - np.max(gain_dev)) <= (1e-6 if f32 else 0.0)):
             raise SystemExit(f"bench result failed its parity guard: {verify}")
 
     if rank == 0:
-        updates_per_step = n_global * N_FIELDS * N_ZSTEPS
+        facts = profile_facts().get(args.config, {})
+        updates_per_step = n_global * nw * n_z
         value = updates_per_step * args.steps / wall
-        rk4_steps_per_launch = PTS_PER_GPU * N_ZSTEPS
-        tflops = FLOPS_PER_RK4_STEP * rk4_steps_per_launch / (kern_ms * 1e-3) / 1e12
-        alg_bytes = BYTES_PER_POINT * PTS_PER_GPU
+        rk4_steps_per_launch = pts * n_z
+        flops = FLOPS_PER_RK4_STEP[nw] * rk4_steps_per_launch
+        tflops = flops / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[cfg["dtype"]]
+        alg_bytes = sweep.layout.bytes_per_point() * pts + sweep.layout.es * pts * (2 if nw == 6 else 1)   # record + dbeta
         gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = measured_traffic()
+        ipw = facts.get("valu_insts_per_wave_step")
+        # lanes that carry one sweep point: 1 (one lane per point), 0.5 (float32 packed: two points per lane), 2 (split)
+        lanes_per_point = facts.get("lanes_per_point", 1.0)
         out = {
             "metric": "RK4 field-point updates/sec (sweep_pts x n_fields x n_zsteps / wall_s)",
             "value": value, "unit": "field-point updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 65536 dbeta sweep points x 4 fields x 100000 z-steps, float64, "
-                                   "per GPU (C2 inputs of SURVEY 8d)", "sweep_pts_per_gpu": PTS_PER_GPU,
-                       "sweep_pts_total": n_global, "n_fields": N_FIELDS, "n_zsteps": N_ZSTEPS, "save_every": SAVE_EVERY,
-                       "check_nan": True, "parallelism": f"sweep sharded x{world}, one RCCL all_gather per pass"
-                       if world > 1 else "single GPU"},
-            "rk4_steps_per_s": value / N_FIELDS,
+            "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": f"BASELINE {cfg['baseline']}: {cfg['what']}", "name": args.config,
+                       "sweep_pts_per_gpu": pts, "sweep_pts_total": n_global, "n_fields": nw, "n_zsteps": n_z,
+                       "save_every": SAVE_EVERY, "check_nan": True,
+                       "parallelism": f"sweep sharded x{world}, one RCCL all_gather per pass" if world > 1 else "single GPU"},
+            "rk4_steps_per_s": value / nw,
             "roofline": {
-                "kernel": "psa::rk4_sweep_kernel<double, 4, CHECK_BLOCK, false, 256>",
+                "kernel": facts.get("kernel"),
                 "bound": "mfma",   # the contract's label for the COMPUTE roofline (enum hbm | mfma); see bound_detail
-                "bound_detail": "compute-bound on the FP64 VECTOR ALU: the kernel issues 0 MFMA instructions (elementwise "
-                                "complex recurrence, nothing to contract); MI355X FP64 vector and FP64 matrix dense peaks "
-                                "are both 78.6 TFLOP/s, so the peak is the same number either way",
-                "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_VALU_TFLOPS,
-                "flops_per_launch": FLOPS_PER_RK4_STEP * rk4_steps_per_launch,
-                "kernel_ms_avg": kern_ms,
-                # 301.8 FP64 wave-instructions per z-step per wave (SQ_INSTS_VALU, profiles/README.md) x 4 issue cycles:
-                # the clock the chip would need if the FP64 pipe never idled = a LOWER bound on the clock it held.  Boxes of
-                # the pool differ by ~10 % here (DVFS / silicon), which moves `frac` with no change in the code.
-                "fp64_issue_ghz_equiv": 301.8 * 4 * N_ZSTEPS / (kern_ms * 1e-3) / 1e9,
-                "traffic": None if traffic is None else traffic.get("bytes_per_launch"),
-                "traffic_source": None if traffic is None else traffic.get("source"),
-                "note": "elementwise complex recurrence: no MFMA, ~2e-4 B per update -> FP64 vector issue is the binding "
-                        "roofline (DESIGN.md section 5); the HBM view of the same launch follows",
+                "bound_detail": "compute-bound on the VECTOR ALU: the kernel issues 0 MFMA instructions (elementwise complex "
+                                "recurrence, nothing to contract); for float64 the MI355X vector and matrix dense peaks are "
+                                "the same 78.6 TFLOP/s, for float32 the peak used is the packed-vector rate 157.3 TFLOP/s",
+                "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                "flops_per_launch": flops, "flops_per_rk4_step": FLOPS_PER_RK4_STEP[nw], "kernel_ms_avg": kern_ms,
+                # VALU wave-instructions per z-step (SQ_INSTS_VALU, profiles/kernels.json) x 4 issue cycles: the clock the chip
+                # would need if the vector pipe never idled = a LOWER bound on the clock it held.  Boxes of the pool differ
+                # by ~10 % here (DVFS / silicon), which moves `frac` with no change in the code.
+                "valu_issue_ghz_equiv": None if ipw is None else ipw * 4 * n_z / (kern_ms * 1e-3) / 1e9,
+                "valu_insts_per_wave_step": ipw, "lanes_per_point": lanes_per_point,
+                "traffic": facts.get("hbm_bytes_per_launch"), "traffic_source": facts.get("source"),
+                "note": "elementwise complex recurrence: no MFMA, ~2e-4 B per update -> vector issue is the binding roofline "
+                        "(DESIGN.md section 5); the HBM view of the same launch follows",
                 "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             },
@@ -317,10 +417,7 @@ def main() -> None:
             out["gpu_over_cpu"] = value / cpu_leg["value"]
         if use_dist:
             torch.cuda.synchronize()
-        sys.stdout.flush()
-        os.dup2(saved_stdout_fd, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        emit(out, saved_stdout_fd)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

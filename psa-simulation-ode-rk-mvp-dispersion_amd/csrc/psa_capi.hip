@@ -118,6 +118,9 @@ int sweep_dev(void *stream, int n_waves, int64_t n_points, int64_t n_steps, doub
                              d_a0_soa, d_a_end_soa, d_p_end, d_p_max, d_first_bad);
     if (rc != PSA_OK) return rc;
     if (n_points == 0) return PSA_OK;
+    // trajectory rows are addressed as (row, wave) base + a 32-bit byte offset per lane
+    if (d_traj_soa && (unsigned long long)n_points * (2 * sizeof(T)) >= (1ull << 32))
+        return fail(PSA_E_TOO_LARGE, "a trajectory launch takes at most %llu points", (1ull << 32) / (2 * sizeof(T)) - 1);
     auto a = make_args<T>(n_waves, n_points, n_steps, z_max, save_every, d_dbeta, d_dbeta2, d_gamma, d_alpha,
                           d_a0_soa, flags, d_a_end_soa, d_p_end, d_p_max, d_first_bad, d_traj_soa);
     hipError_t e = Launch<T>::sweep((hipStream_t)stream, n_waves, check_mode(flags), (flags & PSA_OPT_LDS_STAGING) != 0,

@@ -12,7 +12,8 @@
 //   * no transcendental in the steady-state loop: E(z) = 2*gamma*exp(i*dbeta*z) is carried by a
 //     complex rotation per half step and re-seeded from an exact sincos once RESYNC steps have passed
 //     (checked between 32-step chunks: every <= 96 steps; drift ~2e-14, far inside the 1e-9 parity budget),
-//   * <= 128 VGPRs so 4 waves/SIMD stay resident, all per-lane arrays statically indexed,
+//   * all per-lane arrays statically indexed and in VGPRs (178 for the bench instantiation: 2 waves/SIMD; capping
+//     at 168 (3 waves) or 128 (4 waves, 16 spilled) was measured no faster -- the loop is issue-bound),
 //   * wave-uniform control flow only (save stride, resync and NaN tracking never diverge),
 //   * SoA global layout: every load/store instruction of a wave is one contiguous 512-B run.
 //
@@ -33,6 +34,16 @@ __device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __buil
 template <typename T> struct PairOf;
 template <> struct PairOf<double> { typedef double type __attribute__((ext_vector_type(2))); };
 template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
+// Streaming store of one (re, im) pair at  sbase + voff : sbase wave-uniform (an SGPR pair), voff the lane's 32-bit byte
+// offset.  This is the global_store "saddr" form; written as inline assembly because the compiler, left to itself, widens
+// the lane offset to 64 bits inside the z-loop and then spends a v_lshl_add_u64 per store on the address.
+__device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<double>::type v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<float>::type v) {
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 
 // cos/sin of a float64 phase, delivered in the working precision.
 template <typename T> struct Phase;
@@ -197,12 +208,17 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;  // the tail only matters for check_nan
 
     // trajectory rows: device layout [row][wave][N][2] -- each lane stores one (re, im) pair = 16 B (f64), so a wave
-    // instruction writes 1 KiB contiguously (the widest coalesced store; half the store instructions of per-component rows)
+    // instruction writes 1 KiB contiguously (the widest coalesced store; half the store instructions of per-component rows).
+    // The wave-uniform part of the address (row, wave) stays in SGPRs and the lane contributes a 32-bit byte offset
+    // (global_store ... saddr form): no vector instruction is spent on addressing.  The C-ABI keeps N * sizeof(Pair) < 2^32
+    // for trajectory launches.
     using Pair = typename PairOf<T>::type;
+    const unsigned lane_off = (unsigned)idx * (unsigned)sizeof(Pair);
     auto store_traj_row = [&](const int r) {
-        Pair *dst = reinterpret_cast<Pair *>(A.traj) + (long long)r * NW * N + idx;
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
 #pragma unroll
-        for (int j = 0; j < NW; ++j) __builtin_nontemporal_store(Pair{y[2 * j], y[2 * j + 1]}, dst + (long long)j * N);
+        for (int j = 0; j < NW; ++j)
+            store_pair_nt(rowb + (long long)j * N * (long long)sizeof(Pair), lane_off, Pair{y[2 * j], y[2 * j + 1]});
     };
     if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) {
@@ -332,6 +348,60 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
         else rk4_step_classic(step_index);
     };
 
+    auto write_summary = [&]() {
+        A.p_end[idx] = pe;
+        A.p_max[idx] = pm;
+        A.first_bad[idx] = bad;
+    };
+    auto seed_phase = [&](const int step) {   // exact re-seed of the phase recurrence at z = step * h (wave-uniform)
+        const double z = (double)step * hd;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            T c, s;
+            Phase<T>::eval(dbd[p] * z, c, s);
+            Er[p] = e_amp * c;
+            Ei[p] = e_amp * s;
+        }
+    };
+
+    // ---- save_every == 1 with a trajectory: EVERY step is a saved row (integrators.py:137), the path's HBM-bound regime
+    // (64 B per point per step against ~300 FP64 instructions: right at the ridge).  A dedicated loop keeps the per-row
+    // work to what the row needs -- |A_sig|^2, a running maximum, the block-mode finite test, four streaming stores -- with
+    // no event bookkeeping between steps, two steps per trip so the stores of one row issue under the next step.
+    if constexpr (TRAJ && !LDS) {
+        if (se == 1) {
+            auto save_row = [&](const int r) {
+                pe = fma_(y[4], y[4], y[5] * y[5]);
+                pm = pe > pm ? pe : pm;               // NaN is made to propagate after the loop (it is sticky in y)
+                if constexpr (CHECK == CHECK_BLOCK) {
+                    if (bad < 0 && any_nonfinite<T, NC>(y)) bad = r - 1;
+                }
+                store_traj_row(r);
+            };
+            int i = 0;
+            while (i < n_run) {                       // n_run == n_steps == n_rows
+                seed_phase(i);
+                const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
+                for (; i + 2 <= end; i += 2) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    rk4_step(i + 1);
+                    save_row(i + 2);
+                }
+                if (i < end) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    ++i;
+                }
+            }
+            if (pe != pe) pm = pe;                    // np.max over the saved rows propagates NaN
+#pragma unroll
+            for (int c = 0; c < NC; ++c) A.a_end[(long long)c * N + idx] = y[c];
+            write_summary();
+            return;
+        }
+    }
+
     // ---- z-loop, event driven: the steps between two events (a saved row, a phase re-seed, the end) run in a
     // branch-free 2x-unrolled inner loop.  With one wave per SIMD (65 536 points fill the chip exactly once) every
     // taken branch is an exposed instruction refetch, so per-step `if`s cost ~6 % -- see DESIGN.md section 5.
@@ -342,14 +412,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
     while (i < n_run) {
         if (since_seed >= RESYNC) {    // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
-            const double z = (double)i * hd;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                T c, s;
-                Phase<T>::eval(dbd[p] * z, c, s);
-                Er[p] = e_amp * c;
-                Ei[p] = e_amp * s;
-            }
+            seed_phase(i);
             since_seed = 0;
         }
         int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;   // no overflow near 2^31 steps
@@ -387,9 +450,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     if constexpr (CHECK == CHECK_BLOCK) {  // covers the unsaved tail
         if (bad < 0 && n_run > 0 && any_nonfinite<T, NC>(y)) bad = n_run - 1;
     }
-    A.p_end[idx] = pe;
-    A.p_max[idx] = pm;
-    A.first_bad[idx] = bad;
+    write_summary();
 }
 
 template <typename T, int NW, int CHECK, bool TRAJ>

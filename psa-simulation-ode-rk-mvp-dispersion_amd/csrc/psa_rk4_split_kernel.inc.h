@@ -32,6 +32,10 @@ __device__ __forceinline__ double from_partner(const double v) {
     return __hiloint2double(hi, lo);
 }
 
+// (A/B, DESIGN.md 5.2: routing the exchanges that have slack -- the other pump, the other pair's driving term -- through
+// the LDS crossbar with ds_swizzle_b32 frees 32 VALU slots per step but its latency is exposed with one wave per SIMD:
+// 12.50 ms instead of 11.73 ms on the config-5 shard shape.  All exchanges stay DPP moves.)
+
 // out = base + c * dA/dz(a) for the lane's own waves (stage coefficient folded into g, tg, ha, E as in yaman_stage).
 // NL = waves per lane (2 | 3); a = [Re, Im] x NL in the lane's order given above.
 template <int NL, bool LOSS>

@@ -381,22 +381,68 @@ def test_full_size_c3_grid_sampled_parity(oracle):
     np.testing.assert_allclose(P.sum(1), 0.2000002 * np.exp(-alpha * L), rtol=1e-10)
 
 
+def _six_wave_invariants(a_end, P6, alpha, L, rtol):
+    """What the six-wave equations conserve up to the common loss factor exp(-alpha L): the total power and
+    the Manley-Rowe differences |s_k|^2 - |i_k|^2 (k = 1, 2) and |p1|^2 - |p2|^2 -- every photon pair taken from the two
+    pumps goes into one signal/idler pair."""
+    P = np.abs(a_end) ** 2
+    decay = np.exp(-alpha * L)
+    np.testing.assert_allclose(P.sum(1), P6.sum() * decay, rtol=rtol)
+    scale = P6.sum() * decay                      # differences of O(1e-6) are held to the same ABSOLUTE accuracy
+    for a, b in ((2, 3), (4, 5), (0, 1)):
+        np.testing.assert_allclose(P[:, a] - P[:, b], (P6[a] - P6[b]) * decay, rtol=0, atol=rtol * scale)
+
+
 def test_config5_shard_shape_six_wave_sampled_parity(oracle):
     """BASELINE config 5 per-GPU shard: 32 768 points (a 128 x 256 slice of the (Omega1, Omega2) grid) x 6 waves x
-    100 000 z-steps, float64.  The 6-wave RHS is build-defined (parity unpinned vs the reference); the kernel must
-    match the oracle's statement of the same equations on sampled points, and total power must decay as exp(-alpha L)."""
+    100 000 z-steps, float64 -- both lane layouts (the library's choice at this size is two lanes per point).  The 6-wave
+    RHS is build-defined (parity unpinned vs the reference); the kernel must match the oracle's statement of the same
+    equations on sampled points, and every point must keep the model's invariants at full length."""
     n, L, alpha = 100_000, 1000.0, 1.15e-4
     d1, d2 = np.meshgrid(np.linspace(-0.03, 0.03, 128), np.linspace(-0.02, 0.04, 256), indexing="ij")
     db, db2 = d1.ravel(), d2.ravel()
     P6 = np.array([0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7])
     a06 = np.sqrt(P6).astype(complex)
-    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=a06, dbeta2=db2)
-    assert (got["first_bad_step"] == -1).all()
     pick = np.random.default_rng(5).choice(db.size, 12, replace=False)
     ref = oracle.sweep(db[pick], z_max=L, n=n, save_every=10, gamma=0.0115, alpha=alpha, a0=a06, dbeta2=db2[pick])
-    assert rel_err(got["a_end"][pick], ref["a_end"]) < RTOL_F64
-    assert rel_err(got["p_max"][pick], ref["p_max"]) < RTOL_F64
-    np.testing.assert_allclose((np.abs(got["a_end"]) ** 2).sum(1), P6.sum() * np.exp(-alpha * L), rtol=1e-10)
+    ms = {}
+    for name, lanes in (("two lanes/point", nat.OPT_SPLIT_POINT), ("one lane/point", nat.OPT_ONE_LANE)):
+        got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=10, gamma=0.0115, alpha=alpha, a0=a06, dbeta2=db2,
+                             extra_flags=lanes)
+        assert (got["first_bad_step"] == -1).all()
+        assert rel_err(got["a_end"][pick], ref["a_end"]) < RTOL_F64
+        assert rel_err(got["p_max"][pick], ref["p_max"]) < RTOL_F64
+        _six_wave_invariants(got["a_end"], P6, alpha, L, 1e-10)
+        ms[name] = got["elapsed_ms"]
+    print("config 5 shard kernel ms:", {k: round(v, 2) for k, v in ms.items()},
+          f"-> x{ms['two lanes/point'] / ms['one lane/point']:.3f}")
+
+
+def test_config5_full_grid_through_the_six_wave_driver(oracle):
+    """BASELINE config 5 whole: scan_six_wave_grid on the real 512 x 512 (Omega1, Omega2) grid, 262 144 points x 6 waves x
+    100 000 z-steps in one launch (~0.4 s).  Invariants on every point, sampled points against the oracle, and the grid's
+    structure: dbeta_1 depends on the row only, dbeta_2 on the column only."""
+    from psa_amd import config, dispersion, frequency_plan, scan_mismtach
+    om = frequency_plan.plan_from_wavelengths(1550e-9, 1558e-9, 1540e-9)
+    sp = frequency_plan.infer_symmetry_from_omegas(*om)
+    d = dispersion.dispersion_params_from_D_S(frequency_plan.lambda_from_omega(sp.omega_c), 0.1, 0.02, 0,
+                                              D_units="ps/nm/km", S_units="ps/nm^2/km", dSdlmbd_units="ps/nm^3/km",
+                                              omega_ref=sp.omega_c)
+    P6 = np.array([0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7])
+    O1, O2 = np.linspace(2e12, 2.4e13, 512), np.linspace(3e12, 2.0e13, 512)
+    cfg = config.custom_simulation_config(z_max=1000.0, dz=0.01)
+    out = scan_mismtach.scan_six_wave_grid(cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, Omega1=O1, Omega2=O2,
+                                           gamma=0.0115, alpha=1.15e-4, p_in=P6, dispersion=d, gain_unit="linear")
+    assert out["gain"].shape == (512, 512) and (out["first_bad_step"] == -1).all()
+    assert out["result"].n_steps == 100_000
+    _six_wave_invariants(out["a_end"].reshape(-1, 6), P6, 1.15e-4, 1000.0, 1e-10)
+    rng = np.random.default_rng(55)
+    for iy, ix in zip(rng.integers(0, 512, 10), rng.integers(0, 512, 10)):
+        ref = oracle.sweep(np.array([out["dbeta1"][iy]]), dbeta2=np.array([out["dbeta2"][ix]]), z_max=1000.0, n=100_000,
+                           save_every=10, gamma=0.0115, alpha=1.15e-4, a0=np.sqrt(P6).astype(complex))
+        assert rel_err(out["a_end"][iy, ix], ref["a_end"][0]) < RTOL_F64
+        assert out["gain"][iy, ix] == pytest.approx(ref["p_max"][0] / P6[2], rel=RTOL_F64)
+    assert out["gain"].max() > 10.0                  # the grid crosses pair 1's phase-matched band
 
 
 def test_config4_per_gpu_shard_at_full_length_float32(oracle):

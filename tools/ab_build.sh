@@ -12,6 +12,6 @@ mkdir -p $ROOT/ab
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$CSRC -Wall -Wno-unused-function "$@" \
     -c $CSRC/psa_rk4_f64.hip -o $ROOT/ab/psa_rk4_f64_$TAG.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/ab/libpsa_hip_$TAG.so $ROOT/ab/psa_rk4_f64_$TAG.o \
-    $CSRC/psa_rk4_f32.o $CSRC/psa_aux.o $CSRC/psa_capi.o
+    $CSRC/psa_rk4_f32.o $CSRC/psa_aux.o $CSRC/psa_dbeta.o $CSRC/psa_capi.o
 rm -f $ROOT/ab/psa_rk4_f64_$TAG.o
 echo built ab/libpsa_hip_$TAG.so

@@ -37,7 +37,7 @@ def worker(tag):
         print(f"[{tag}] trajectory N=262144 n=100 se=1: {ms:.3f} ms -> {262144*101*64/ms/1e6:.0f} GB/s", flush=True)
         ms = t(1 << 20, 50, a4, reps=2, save_every=1, z_max=0.5, want_traj=True)
         print(f"[{tag}] trajectory N=2^20 n=50 se=1: {ms:.3f} ms -> {(1<<20)*51*64/ms/1e6:.0f} GB/s", flush=True)
-    if tag in ("base", "head"):
+    if True:
         for nw, a0 in ((4, a4), (6, a6)):
             for N in (1, 4096, 32768):
                 n = 20000

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "psa-simulation-ode-rk-mvp-dispersion_amd", "csrc")
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{ROOT}/include", f"-I{CSRC}",
-       *(["-mllvm", "-amdgpu-sched-strategy=" + os.environ["SCHED"]] if os.environ.get("SCHED", "max-ilp") != "default" else []), "-Rpass-analysis=kernel-resource-usage", "-c",
+       *(["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("SCHED", "max-ilp")] if os.environ.get("SCHED", "max-ilp") != "default" else []), "-Rpass-analysis=kernel-resource-usage", "-c",
        os.path.join(CSRC, src), "-o", "/tmp/_kr.o"] + sys.argv[2:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], {}

@@ -28,6 +28,34 @@ def one(pattern):
     return hits[0] if hits else None
 
 
+def db_kernel_stats(db):
+    """rocprofv3's default output on this image is a rocpd SQLite database: the per-kernel table of --stats from it."""
+    import sqlite3
+    con = sqlite3.connect(db)
+    per = {}
+    for name, dur in con.execute("select name, duration from kernels"):
+        per.setdefault(name, []).append(float(dur))
+    total = sum(sum(v) for v in per.values())
+    rows = []
+    for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        rows.append({"Name": name, "Calls": len(v), "TotalDurationNs": sum(v), "AverageNs": sum(v) / len(v),
+                     "Percentage": 100.0 * sum(v) / total, "MinNs": min(v), "MaxNs": max(v),
+                     "StdDev": statistics.pstdev(v) if len(v) > 1 else 0.0})
+    return rows
+
+
+def db_counters(db, kernel):
+    """-> ({counter: {dispatch: value}}, {dispatch: duration_ms}) of one kernel (values summed over XCDs / instances)."""
+    import sqlite3
+    con = sqlite3.connect(db)
+    counters, durations = {}, {}
+    for disp, cname, value, start, end in con.execute(
+            "select dispatch_id, counter_name, value, start, end from counters_collection where kernel_name = ?", (kernel,)):
+        counters.setdefault(cname, {})[int(disp)] = counters.get(cname, {}).get(int(disp), 0.0) + float(value)
+        durations[int(disp)] = (int(end) - int(start)) / 1e6
+    return counters, durations
+
+
 def main(src, tag):
     out_dir = os.path.join(ROOT, "profiles")
     facts = {}
@@ -36,12 +64,20 @@ def main(src, tag):
         facts = json.load(open(path))
     for cfg in N_Z:
         stats = one(os.path.join(src, f"{cfg}_stats", "**", "*_kernel_stats.csv"))
-        if not stats:
+        stats_db = one(os.path.join(src, f"{cfg}_stats", "**", "*_results.db"))
+        if stats:
+            rows = list(csv.DictReader(open(stats)))
+            shutil.copy(stats, os.path.join(out_dir, f"{tag}_{cfg}_kernel_stats.csv"))
+        elif stats_db:
+            rows = db_kernel_stats(stats_db)
+            with open(os.path.join(out_dir, f"{tag}_{cfg}_kernel_stats.csv"), "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=list(rows[0]), quoting=csv.QUOTE_NONNUMERIC)
+                w.writeheader()
+                w.writerows(rows)
+        else:
             continue
-        rows = list(csv.DictReader(open(stats)))
         dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         kernel = dom["Name"]
-        shutil.copy(stats, os.path.join(out_dir, f"{tag}_{cfg}_kernel_stats.csv"))
         rec = {"kernel": kernel, "calls": int(dom["Calls"]), "avg_ms": float(dom["AverageNs"]) / 1e6,
                "min_ms": float(dom["MinNs"]) / 1e6, "lanes_per_point": LANES_PER_POINT[cfg],
                "source": f"rocprofv3 --kernel-trace --stats / --pmc passes of tools/profile_r02.sh ({tag}), "
@@ -50,13 +86,17 @@ def main(src, tag):
         durations = {}
         for grp in ("sq", "grbm", "fetch", "write"):
             cc = one(os.path.join(src, f"{cfg}_pmc_{grp}", "**", "*_counter_collection.csv"))
-            if not cc:
-                continue
-            for r in csv.DictReader(open(cc)):
-                if r["Kernel_Name"] != kernel:
-                    continue
-                counters.setdefault(r["Counter_Name"], {})[int(r["Dispatch_Id"])] = float(r["Counter_Value"])
-                durations.setdefault(grp, {})[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            cdb = one(os.path.join(src, f"{cfg}_pmc_{grp}", "**", "*_results.db"))
+            if cc:
+                for r in csv.DictReader(open(cc)):
+                    if r["Kernel_Name"] != kernel:
+                        continue
+                    counters.setdefault(r["Counter_Name"], {})[int(r["Dispatch_Id"])] = float(r["Counter_Value"])
+                    durations.setdefault(grp, {})[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            elif cdb:
+                c, d = db_counters(cdb, kernel)
+                counters.update(c)
+                durations[grp] = d
         if counters:
             with open(os.path.join(out_dir, f"{tag}_{cfg}_pmc.csv"), "w", newline="") as f:
                 w = csv.writer(f)

@@ -289,15 +289,25 @@ def main() -> None:
         cpu_leg = cpu_baseline(args.config)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PSA_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks (ranks then share devices and
+    # the gather is staged through the host); the measured configuration is always nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("PSA_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible (RCCL needs one GPU per rank)")
+    local_dev = local_rank % n_dev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     # Under torch.distributed.run (RANK set) the gather path is used even for one rank, so the RCCL plumbing can be
     # rehearsed on a one-GPU box; plain `python bench.py` stays collective-free.
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("PSA_BENCH_DIST_ON_ONE", "0") == "1")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.mode == "trajectory":
         return trajectory_mode(args, dev, saved_stdout_fd)
@@ -333,7 +343,7 @@ def main() -> None:
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if use_dist:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
@@ -389,7 +399,9 @@ def main() -> None:
             "config": {"workload": f"BASELINE {cfg['baseline']}: {cfg['what']}", "name": args.config,
                        "sweep_pts_per_gpu": pts, "sweep_pts_total": n_global, "n_fields": nw, "n_zsteps": n_z,
                        "save_every": SAVE_EVERY, "check_nan": True,
-                       "parallelism": f"sweep sharded x{world}, one RCCL all_gather per pass" if world > 1 else "single GPU"},
+                       "parallelism": (f"sweep sharded x{world}, one RCCL all_gather per pass" if backend == "nccl" else
+                                       f"REHEARSAL: {world} ranks over {n_dev} GPU(s), {backend} gather staged through the host")
+                       if world > 1 else "single GPU"},
             "rk4_steps_per_s": value / nw,
             "roofline": {
                 "kernel": facts.get("kernel"),

@@ -308,6 +308,10 @@ class DeviceSweep:
         """One all_gather of the record over the process group -> (world, words(pad_to)) int64 on this GPU.  Every rank
         must have been built with the same ``pad_to`` (the widest block); trim with ``unpack_gathered``."""
         world = dist.get_world_size(group)
+        if dist.get_backend(group) != "nccl":
+            # rehearsal backend (gloo: several ranks sharing one GPU, or CPU-only hosts): the same words, staged through
+            # the host because gloo has no device-side all_gather_into_tensor
+            return _all_gather_words(self.record.cpu(), world, group).to(self.device)
         with torch.cuda.device(self.device):
             return _all_gather_words(self.record, world, group)
 

@@ -88,8 +88,24 @@ def _wavelength_axis(lam3, unit):
 
 
 # ---- the engine call shared by the drivers ------------------------------------------------------------------
+def _grid_dbeta(lam1, lam2_axis, lam3_axis, disp, pm_cfg, producer, device):
+    """dbeta and validity of every point of the flattened lambda_p2 x lambda_signal grid (row-major).
+    producer "host": the NumPy array restatement (frequency_plan / phase_matching ``*_batch``);
+    producer "device": the same operations on the GPU (psa_dbeta_grid_f64, csrc/psa_dbeta.hip) -- what multi-GPU shards use."""
+    if producer == "device":
+        from . import _native
+        return _native.dbeta_grid_host(_native.dbeta_model(disp, pm_cfg), float(lam1), lam2_axis, lam3_axis, device=device)
+    if producer != "host":
+        raise ValueError("dbeta_producer must be 'host' or 'device'")
+    L2, L3 = np.meshgrid(np.atleast_1d(lam2_axis), np.atleast_1d(lam3_axis), indexing="ij")
+    omega, ok = plan_from_wavelengths_batch(float(lam1), L2.ravel(), L3.ravel())
+    db, ok_db = compute_phase_mismatch_batch(omega, disp, pm_cfg)
+    ok = ok & ok_db
+    return np.where(ok, db, np.nan), ok
+
+
 def _sweep_gain(*, cfg, lam1, lam2, lam3, gamma, alpha, p0, ph0, dispersion, pm_cfg, length_unit, gain_unit,
-                gain_mode="max", device=0):
+                gain_mode="max", device=0, grid_axes=None, dbeta_producer="host"):
     """Everything the reference does inside its per-point ``try``, for all points at once.
 
     Returns (gain[N], dbeta_m[N] per metre, SweepResult | None).  Never raises for per-point or cfg problems:
@@ -103,9 +119,12 @@ def _sweep_gain(*, cfg, lam1, lam2, lam3, gamma, alpha, p0, ph0, dispersion, pm_
                        beta_legacy=None, length_unit=length_unit)
         a0 = make_initial_amplitudes(p0, ph0)
         fiber, grid, pm = pre["fiber"], pre["grid"], pre["pm"].config
-        omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
-        dbeta_m, ok_db = compute_phase_mismatch_batch(omega, fiber.dispersion, pm)
-        ok &= ok_db
+        if grid_axes is not None:      # (lambda_p2 axis, lambda_signal axis) of a 2-D grid: lam2 / lam3 are its flattening
+            dbeta_m, ok = _grid_dbeta(lam1, grid_axes[0], grid_axes[1], fiber.dispersion, pm, dbeta_producer, device)
+        else:
+            omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
+            dbeta_m, ok_db = compute_phase_mismatch_batch(omega, fiber.dispersion, pm)
+            ok &= ok_db
         n_steps = n_steps_of(fiber.length_m, grid.dz_m)
         if n_steps < 1:
             raise ValueError("no steps")
@@ -279,8 +298,10 @@ def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Se
                    lambda_signal_m: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
                    phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
                    phase_matching_cfg: Optional[PhaseMatchingConfig] = None, length_unit: str = "m",
-                   gain_unit: str = "dB", gain_mode: GainMode = "max", device: int = 0) -> dict:
+                   gain_unit: str = "dB", gain_mode: GainMode = "max", device: int = 0,
+                   dbeta_producer: str = "host") -> dict:
     """Signal gain over the grid lambda_p2[Ny] x lambda_signal[Nx]: Ny*Nx independent runs, one kernel launch.
+    ``dbeta_producer="device"`` computes the grid's phase mismatch on the GPU as well (same operations, see _grid_dbeta).
 
     Row iy is exactly what ``plot_max_gain_and_dbeta_vs_lambda_signal(lambda_p2_m=lambda_p2[iy], ...)`` returns
     (same plans, same dbeta, same NaN rules).  Returns dict(gain (Ny, Nx), dbeta (Ny, Nx) in 1/length_unit,
@@ -296,17 +317,17 @@ def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Se
     if dispersion is None:
         raise ValueError("dispersion must be provided")
     pm_cfg = phase_matching_cfg if phase_matching_cfg is not None else PhaseMatchingConfig()
+    if dbeta_producer not in ("host", "device"):
+        raise ValueError("dbeta_producer must be 'host' or 'device'")
     L2, L3 = np.meshgrid(lam2, lam3, indexing="ij")
     l2, l3 = L2.ravel(), L3.ravel()
     try:
-        omega, ok = plan_from_wavelengths_batch(float(lambda_p1_m), l2, l3)
-        dbeta, ok_db = compute_phase_mismatch_batch(omega, dispersion, pm_cfg)
-        dbeta = np.where(ok & ok_db, dbeta, np.nan)
+        dbeta, _ = _grid_dbeta(float(lambda_p1_m), lam2, lam3, dispersion, pm_cfg, dbeta_producer, device)
     except Exception:
         dbeta = np.full(l3.shape, np.nan)
     gain, _, res = _sweep_gain(cfg=cfg, lam1=float(lambda_p1_m), lam2=l2, lam3=l3, gamma=gamma, alpha=alpha, p0=p0,
                                ph0=ph0, dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
-                               gain_mode=gain_mode, device=device)
+                               gain_mode=gain_mode, device=device, grid_axes=(lam2, lam3), dbeta_producer=dbeta_producer)
     gain = np.where(np.isnan(dbeta), np.nan, gain)
     finite = np.isfinite(gain)
     best = None
@@ -322,7 +343,7 @@ def scan_six_wave_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m
                        Omega2: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
                        phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
                        even_orders: Tuple[int, ...] = (2, 4), length_unit: str = "m", gain_unit: str = "dB",
-                       gain_mode: GainMode = "max", device: int = 0) -> dict:
+                       gain_mode: GainMode = "max", device: int = 0, dbeta_producer: str = "host") -> dict:
     """Six waves [p1, p2, s1, i1, s2, i2]: pair k sits at omega_c +- Omega_k (omega_c, omega_d from the two pumps) and
     has dbeta_k = sum_{n even} beta_n (Omega_k^n - omega_d^n) 2/n!  (the symmetric-even form, dispersion.py:321-372).
     Runs the Omega1[Ny] x Omega2[Nx] grid in ONE launch of the 6-wave kernel.
@@ -357,9 +378,17 @@ def scan_six_wave_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m
     disp_m, fiber, grid = pre["fiber"].dispersion, pre["fiber"], pre["grid"]
     db1 = delta_beta_symmetric_array(wd, O1, disp_m, even_orders=even_orders)      # per metre
     db2 = delta_beta_symmetric_array(wd, O2, disp_m, even_orders=even_orders)
-    D1, D2 = np.meshgrid(db1, db2, indexing="ij")
+    if dbeta_producer == "device":       # the whole grid's (dbeta_1, dbeta_2) from the GPU producer (psa_dbeta_pairs_f64)
+        from . import _native
+        d1_flat, d2_flat = _native.dbeta_pairs_host(_native.dbeta_model(disp_m, None, even_orders=even_orders), wd, O1, O2,
+                                                    device=device)
+    elif dbeta_producer == "host":
+        D1, D2 = np.meshgrid(db1, db2, indexing="ij")
+        d1_flat, d2_flat = D1.ravel(), D2.ravel()
+    else:
+        raise ValueError("dbeta_producer must be 'host' or 'device'")
     from .sweep import initial_amplitudes
-    res = rk4_sweep(D1.ravel(), dbeta2=D2.ravel(), z_max=fiber.length_m, dz=grid.dz_m, save_every=cfg.save_every,
+    res = rk4_sweep(d1_flat, dbeta2=d2_flat, z_max=fiber.length_m, dz=grid.dz_m, save_every=cfg.save_every,
                     check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m,
                     a0=initial_amplitudes(p0, ph), device=device)
     gain = res.gain(p0[2], mode=gain_mode, unit=unit, device=device)

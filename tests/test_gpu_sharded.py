@@ -179,3 +179,79 @@ def test_sweep_sharded_float32_and_six_waves_through_rccl(oracle, rccl_one_rank)
     ref6 = oracle.sweep(db, dbeta2=-0.4 * db, z_max=200.0, n=2000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6)
     assert r6.a_end.shape == (501, 6) and rel_err(r6.a_end, ref6["a_end"]) < RTOL_F64
     assert np.array_equal(r6.first_bad_step, ref6["first_bad_step"])
+
+
+def _shard_object_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for q in (root, os.path.join(root, "oracle")):
+        sys.path.insert(0, q)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import psa_amd._native as nat
+        from psa_amd import dispersion
+        from psa_amd.distributed import DeviceSweep, shard_bounds, unpack_gathered
+        from psa_amd.phase_matching import PhaseMatchingConfig
+        lam2 = np.linspace(1552e-9, 1562e-9, 11)
+        lam3 = np.linspace(1540e-9, 1565e-9, 23)
+        N = lam2.size * lam3.size                                       # 253 = 85 + 84 + 84
+        d = dispersion.dispersion_params_from_D_S(1554e-9, 0.1, 0.02, 0.0, D_units="ps/nm/km", S_units="ps/nm^2/km",
+                                                  dSdlmbd_units="ps/nm^3/km")
+        lo, hi = shard_bounds(N, world, rank)
+        out = {}
+        for name, dtype in (("f64", np.float64), ("f32", np.float32)):
+            ds = DeviceSweep(n_local=hi - lo, n_steps=2000, z_max=200.0, save_every=10, gamma=0.0115, alpha=1.15e-4,
+                             a0=np.sqrt([0.1, 0.1, 1e-7, 1e-7]).astype(complex), dtype=dtype, pad_to=(N + world - 1) // world,
+                             device=torch.device("cuda", 0))
+            ds.fill_dbeta_grid(nat.dbeta_model(d, PhaseMatchingConfig()), 1550e-9, lam2, lam3, first=lo)
+            ds.launch()
+            g = ds.gather()                                             # gloo: staged through the host, same words
+            torch.cuda.synchronize()
+            a, pe, pm, fb = unpack_gathered(ds.layout, g.cpu().numpy(), N, world)
+            db_all = [torch.zeros((N + world - 1) // world, dtype=ds.dbeta.dtype) for _ in range(world)]
+            mine = torch.zeros((N + world - 1) // world, dtype=ds.dbeta.dtype)
+            mine[:hi - lo] = ds.dbeta.cpu()
+            dist.all_gather(db_all, mine)
+            out.update({f"a_{name}": a, f"pm_{name}": pm, f"fb_{name}": fb,
+                        f"db_{name}": np.concatenate([t.numpy()[:shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0]]
+                                                      for r, t in enumerate(db_all)])})
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_generate_their_blocks_and_gather_ragged_records(tmp_path, oracle):
+    """The 8-GPU code path with three processes on this box's one GPU: every rank builds the shard object for its RAGGED
+    block (85 / 84 / 84 points), generates the block's dbeta on the device from the grid definition, runs the kernel and
+    gathers the zero-padded records (gloo carries the words; RCCL needs a GPU per rank).  Every rank must end up with the
+    whole sweep, equal to the oracle on the host-generated grid -- float64 and float32 records."""
+    import torch.multiprocessing as mp
+    from psa_amd import dispersion, frequency_plan, phase_matching
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_shard_object_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    r = [np.load(tmp_path / f"r{k}.npz") for k in range(3)]
+    for k in (1, 2):
+        for key in r[0].files:
+            assert np.array_equal(r[0][key], r[k][key], equal_nan=True), (k, key)
+    lam2, lam3 = np.linspace(1552e-9, 1562e-9, 11), np.linspace(1540e-9, 1565e-9, 23)
+    d = dispersion.dispersion_params_from_D_S(1554e-9, 0.1, 0.02, 0.0, D_units="ps/nm/km", S_units="ps/nm^2/km",
+                                              dSdlmbd_units="ps/nm^3/km")
+    L2, L3 = np.meshgrid(lam2, lam3, indexing="ij")
+    om, ok = frequency_plan.plan_from_wavelengths_batch(1550e-9, L2.ravel(), L3.ravel())
+    db, ok2 = phase_matching.compute_phase_mismatch_batch(om, d, phase_matching.PhaseMatchingConfig())
+    assert ok.all() and ok2.all()
+    np.testing.assert_allclose(r[0]["db_f64"], db, rtol=3e-16)
+    assert np.array_equal(r[0]["db_f32"], r[0]["db_f64"].astype(np.float32))       # the float32 producer rounds the float64 value
+    a0 = np.sqrt([0.1, 0.1, 1e-7, 1e-7]).astype(complex)
+    ref = oracle.sweep(r[0]["db_f64"], z_max=200.0, n=2000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    assert r[0]["a_f64"].shape == (253, 4) and rel_err(r[0]["a_f64"], ref["a_end"]) < RTOL_F64
+    assert rel_err(r[0]["pm_f64"], ref["p_max"]) < RTOL_F64 and (r[0]["fb_f64"] == -1).all()
+    ref32 = oracle.sweep(r[0]["db_f32"].astype(np.float64), z_max=200.0, n=2000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
+    assert r[0]["a_f32"].dtype == np.complex64 and rel_err(r[0]["a_f32"].astype(complex), ref32["a_end"]) < RTOL_F32

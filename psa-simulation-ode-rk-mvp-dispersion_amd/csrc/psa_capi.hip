@@ -425,7 +425,7 @@ int psa_device_count(void) {
     return n;
 }
 const char *psa_last_error(void) { return g_err; }
-const char *psa_version(void) { return "psa-hip 0.1.0 gfx950"; }
+const char *psa_version(void) { return "psa-hip 0.2.0 gfx950"; }
 int64_t psa_n_saved(int64_t n_steps, int32_t save_every) {
     if (n_steps < 0 || save_every <= 0) return -1;
     return n_steps / save_every + 1;

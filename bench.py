@@ -379,7 +379,7 @@ def main() -> None:
             raise SystemExit(f"bench result failed its parity guard: {verify}")
 
     if rank == 0:
-        facts = profile_facts().get(args.config, {})
+        facts = profile_facts().get("c5one" if (args.config == "c5" and args.one_lane) else args.config, {})
         updates_per_step = n_global * nw * n_z
         value = updates_per_step * args.steps / wall
         rk4_steps_per_launch = pts * n_z

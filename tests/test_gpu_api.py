@@ -282,6 +282,16 @@ def test_the_ctypes_stub_printed_in_integration_md_runs(golden):
     assert (bad == -1).all() and traj is None
     a1, _, _, b1, t1 = stub.rk4_sweep([0.013], 0.0115, 1.15e-4, np.sqrt(g["p_in"]).astype(complex), 100.5, 1005, 10, want_traj=True)
     assert t1.shape == (1, 101, 4) and np.array_equal(t1[0, -1], a1[0])
+    # section B4 of the same document: the dbeta producer bound the same way, against the reference's own dbeta (G2)
+    b4 = re.search(r"```python\n(_L\.psa_dbeta_grid_f64\.restype.*?)```", doc, re.S).group(1)
+    from psa_amd import constants
+    stub.constants = constants
+    exec(compile(b4, "INTEGRATION.md:B4", "exec"), stub.__dict__)
+    g2 = golden("G2")
+    d = dispersion.DispersionParams(omega_ref=float(g2["omega_ref"]), beta2=float(g2["beta2"]), beta3=float(g2["beta3"]),
+                                    beta4=float(g2["beta4"]))
+    db, ok = stub.dbeta_grid(d, float(g2["lambda_p1"]), [float(g2["lambda_p2"])], g2["lambda3"])
+    assert ok.all() and np.all(np.abs(db - g2["dbeta"]) <= np.spacing(np.abs(g2["dbeta"])))
 
 
 def test_device_entry_point_can_be_captured_into_a_graph_and_replayed(oracle):

@@ -532,3 +532,32 @@ def test_extreme_parameters(oracle):
         assert np.all(got["a_end"][0, 2:] == 0) and np.all(got["a_end"][1, :2] == 0)
         live = ref["p_max"] > 0
         assert rel_err(got["p_max"][live], ref["p_max"][live]) < 1e-7
+
+
+def test_trajectory_leaves_the_device_in_chunks(oracle):
+    """Host-buffer API: a 453 MB trajectory (70 001 points x 101 rows) is transposed and copied in two chunks through the
+    bounded staging buffers (psa_capi.hip, TRAJ_STAGE_BYTES = 256 MB), the second one ragged (not a multiple of the 32-point
+    transpose tile).  Rows of points on both sides of the chunk boundary against the oracle; A[-1] == last row everywhere."""
+    N, n = 70_001, 100
+    db = np.linspace(-0.06, 0.06, N)
+    got = nat.sweep_host(db, n_steps=n, z_max=10.0, save_every=1, gamma=0.0115, alpha=1.15e-4, a0=A0, want_traj=True)
+    assert got["traj"].shape == (N, n + 1, 4)
+    assert np.array_equal(got["traj"][:, -1, :], got["a_end"]) and np.all(got["traj"][:, 0, :] == A0)
+    boundary = (256 * 2**20 // ((n + 1) * 64)) // 32 * 32            # first point of the second chunk
+    for i in (0, 31, 32, boundary - 1, boundary, boundary + 1, N - 2, N - 1):
+        z, A, _ = oracle.integrate(A0, z_max=10.0, n=n, save_every=1, gamma=0.0115, alpha=1.15e-4, dbeta=db[i])
+        assert rel_err(got["traj"][i], A) < RTOL_F64, i
+
+
+def test_a_trajectory_that_cannot_fit_is_refused_before_any_allocation():
+    """PSA_E_TOO_LARGE (-9), not hipErrorOutOfMemory: 2^27 points x 100 001 rows = 8.6e14 B.  The call returns from its
+    size check, so the small dummy buffers are never read or written."""
+    import ctypes as C
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    L = nat.lib()
+    flags = nat.BCAST_GAMMA | nat.BCAST_ALPHA | nat.BCAST_A0
+    rc = L.psa_rk4_sweep_f64(0, 4, 2**27, 100_000, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p, None)
+    assert rc == -9 and b"does not fit" in L.psa_last_error()
+    rc = L.psa_rk4_sweep_f64_dev(None, 4, 2**28, 10, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p)
+    assert rc == -9                                                   # trajectory launches address lanes with 32 bits

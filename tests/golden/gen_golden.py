@@ -21,6 +21,9 @@ Fixture ids follow SURVEY.md section 8(c):
   G10 dbeta producer cases (unit variants, GENERAL_TAYLOR, dS/dlambda != 0 quirk)
   G11 driver variants: km units, linear gain, non-zero input phases
   G12 a run bundle written by the reference's io_fwm (npz + csv + json): pins the file format
+  G13 paths the other fixtures do not walk: legacy beta(w_j) fallback (m and km), GENERAL_TAYLOR through the single run and
+      through the gain+dbeta driver, and a 4 x 9 (lambda_p2 x lambda_signal) grid run row by row through the reference's
+      driver (pins the build's 2-D grid scan and its device-side dbeta producer against the reference itself)
 """
 from __future__ import annotations
 
@@ -366,6 +369,53 @@ def gen_g11(pool):
           km_dbeta=np.concatenate([r[2] for r in rk]))
 
 
+def _g13_row(args):
+    import config, scan_mismtach as sm
+    from dispersion import DispersionParams
+    from phase_matching import PhaseMatchingConfig, PhaseMatchingMethod
+    (lp2, lam3, dt, method) = args
+    disp = DispersionParams(omega_ref=dt[0], beta2=dt[1], beta3=dt[2], beta4=dt[3])
+    cfg = config.custom_simulation_config(z_max=250.0, dz=0.25, save_every=5)
+    pm = None if method == "sym" else PhaseMatchingConfig(method=PhaseMatchingMethod.GENERAL_TAYLOR, max_order=4)
+    x, g, db = sm.plot_max_gain_and_dbeta_vs_lambda_signal(
+        cfg=cfg, lambda_p1_m=1550e-9, lambda_p2_m=lp2, lambda_signal_m=lam3, gamma=0.0115, alpha=1.0e-4,
+        p_in=np.array([0.4, 0.3, 1e-6, 1e-6]), phase_in=None, dispersion=disp, phase_matching_cfg=pm, length_unit="m",
+        return_wavelength_unit="m", gain_unit="dB", show=False, show_progress=False)
+    return g, db
+
+
+def gen_g13(pool):
+    import config, simulation, frequency_plan as fp
+    from phase_matching import PhaseMatchingConfig, PhaseMatchingMethod
+    lam3 = np.linspace(1541e-9, 1566e-9, 9)
+    lam2 = np.linspace(1553e-9, 1561e-9, 4)
+    sp, lam_c, disp = _sweep_setup(1550e-9, 1557e-9, lam3, 0.12)
+    dt = (disp.omega_ref, disp.beta2, disp.beta3, disp.beta4)
+    # (a) legacy betas only: default method becomes PROVIDED with dbeta = b3 + b4 - b1 - b2 (simulation.py, yaman_model.py:112)
+    om = fp.plan_from_wavelengths(1550e-9, 1557e-9, 1545e-9)
+    p_in = np.array([0.4, 0.3, 1e-6, 2e-6])
+    phase = np.array([0.0, 0.7, -0.4, 1.9])
+    b_m = np.array([5.80e6 + 1.0e-3, 5.79e6 - 2.0e-3, 5.81e6 + 4.0e-3, 5.78e6 + 6.0e-3])         # 1/m -> dbeta = 0.011
+    cfg_m = config.custom_simulation_config(z_max=200.0, dz=0.2, save_every=8)
+    z_m, A_m = simulation.run_single_simulation(cfg_m, gamma=0.0115, alpha=1.0e-4, omega=om, p_in=p_in, phase_in=phase,
+                                                beta_legacy=b_m)
+    cfg_km = config.custom_simulation_config(z_max=0.2, dz=0.2e-3, save_every=8)
+    z_km, A_km = simulation.run_single_simulation(cfg_km, gamma=11.5, alpha=0.1, omega=om, p_in=p_in, phase_in=phase,
+                                                  beta_legacy=b_m * 1e3, length_unit="km", return_length_unit="m")
+    # (b) GENERAL_TAYLOR single run
+    pm_gen = PhaseMatchingConfig(method=PhaseMatchingMethod.GENERAL_TAYLOR, max_order=4)
+    z_g, A_g = simulation.run_single_simulation(cfg_m, gamma=0.0115, alpha=1.0e-4, omega=om, p_in=p_in, phase_in=phase,
+                                                dispersion=disp, phase_matching_cfg=pm_gen)
+    # (c), (d) the 4 x 9 grid row by row through the driver: symmetric (default) and GENERAL_TAYLOR
+    rows_sym = pool.map(_g13_row, [(float(l2), lam3, dt, "sym") for l2 in lam2])
+    rows_gen = pool.map(_g13_row, [(float(l2), lam3, dt, "gen") for l2 in lam2])
+    _save("G13", omega=om, p_in=p_in, phase_in=phase, beta_legacy_m=b_m, disp=np.array(dt),
+          legacy_m_z=z_m, legacy_m_A=A_m, legacy_km_z=z_km, legacy_km_A=A_km, gen_z=z_g, gen_A=A_g,
+          lambda2=lam2, lambda3=lam3, grid_p_in=np.array([0.4, 0.3, 1e-6, 1e-6]),
+          grid_gain_sym=np.array([r[0] for r in rows_sym]), grid_dbeta_sym=np.array([r[1] for r in rows_sym]),
+          grid_gain_gen=np.array([r[0] for r in rows_gen]), grid_dbeta_gen=np.array([r[1] for r in rows_gen]))
+
+
 def gen_g12():
     """Files written by the reference's io_fwm.save_run_bundle (tiny: 6 rows) -- pins the on-disk format."""
     import io_fwm
@@ -388,7 +438,7 @@ def main() -> None:
     with Pool(args.procs) as pool:
         for gid, fn, needs_pool in [("G1", gen_g1, False), ("G4", gen_g4, False), ("G5", gen_g5, False),
                                     ("G6", gen_g6, False), ("G7", gen_g7, False), ("G9", gen_g9, False),
-                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("G2", gen_g2, True), ("G3", gen_g3, True),
+                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
                                     ("G11", gen_g11, True), ("G8", gen_g8, True)]:
             if want(gid):
                 print(f"{gid} ... ({time.perf_counter() - t0:.0f}s)", flush=True)

@@ -157,3 +157,31 @@ def test_record_roundtrip_keeps_int64_bits(n_waves, dtype, bytes_per_point):
     assert len({p.size for p in parts}) == 1
     a3, pe3, pm3, b3 = unpack_gathered(lay, np.stack(parts), 5, 3)
     assert np.array_equal(a3, a) and np.array_equal(pm3, pm) and np.array_equal(b3, bad)
+
+
+def test_record_layout_properties_hold_for_arbitrary_splits():
+    """Property test (hypothesis): for any point count, world size, wave count and dtype, packing every rank's block with
+    zero padding to the widest block and unpacking the stacked images returns the original arrays bit for bit, and every
+    image has the same number of int64 words."""
+    from hypothesis import given, settings, strategies as st
+    from psa_amd.distributed import RecordLayout, shard_bounds, unpack_gathered
+
+    @settings(max_examples=60, deadline=None)
+    @given(n=st.integers(0, 70), world=st.integers(1, 9), nw=st.sampled_from([4, 6]), f32=st.booleans(), seed=st.integers(0, 2**31))
+    def check(n, world, nw, f32, seed):
+        lay = RecordLayout(nw, np.float32 if f32 else np.float64)
+        rng = np.random.default_rng(seed)
+        a = (rng.normal(size=(n, nw)) + 1j * rng.normal(size=(n, nw))).astype(lay.cdtype)
+        pe, pm = rng.normal(size=n).astype(lay.dtype), rng.normal(size=n).astype(lay.dtype)
+        bad = rng.integers(-1, 2**40, n)
+        width = (n + world - 1) // world
+        parts = []
+        for r in range(world):
+            lo, hi = shard_bounds(n, world, r)
+            assert 0 <= hi - lo <= width
+            parts.append(lay.pack(a[lo:hi], pe[lo:hi], pm[lo:hi], bad[lo:hi], pad_to=width))
+        assert len({p.size for p in parts}) == 1 and parts[0].size == lay.words(width)
+        a2, pe2, pm2, b2 = unpack_gathered(lay, np.stack(parts), n, world)
+        assert np.array_equal(a2, a) and np.array_equal(pe2, pe) and np.array_equal(pm2, pm) and np.array_equal(b2, bad)
+
+    check()

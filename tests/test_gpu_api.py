@@ -449,3 +449,34 @@ def test_concurrent_host_api_calls_from_four_threads():
     for seq, par in zip(sequential, results):
         assert np.array_equal(seq["a_end"], par["a_end"]) and np.array_equal(seq["p_max"], par["p_max"])
         assert np.array_equal(seq["first_bad_step"], par["first_bad_step"])
+
+
+def test_g13_reference_runs_through_the_legacy_and_taylor_paths(golden):
+    """G13 (generated from the reference): run_single_simulation with only legacy betas (m and km: the reference scales the
+    legacy dbeta twice in km), with GENERAL_TAYLOR, and the 4 x 9 grid through scan_gain_grid with the host AND the device
+    dbeta producer, default and GENERAL_TAYLOR phase matching -- all against the reference's own numbers."""
+    g = golden("G13")
+    kw = dict(omega=g["omega"], p_in=g["p_in"], phase_in=g["phase_in"])
+    cfg_m = config.custom_simulation_config(z_max=200.0, dz=0.2, save_every=8)
+    z, A = simulation.run_single_simulation(cfg_m, gamma=0.0115, alpha=1.0e-4, beta_legacy=g["beta_legacy_m"], **kw)
+    assert rel_err(A, g["legacy_m_A"]) < RTOL_F64 and np.allclose(z, g["legacy_m_z"], rtol=1e-15)
+    cfg_km = config.custom_simulation_config(z_max=0.2, dz=0.2e-3, save_every=8)
+    z, A = simulation.run_single_simulation(cfg_km, gamma=11.5, alpha=0.1, beta_legacy=g["beta_legacy_m"] * 1e3,
+                                            length_unit="km", return_length_unit="m", **kw)
+    assert rel_err(A, g["legacy_km_A"]) < RTOL_F64 and np.allclose(z, g["legacy_km_z"], rtol=1e-13)
+    dv = g["disp"]
+    d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3])
+    gen = PhaseMatchingConfig(method=PhaseMatchingMethod.GENERAL_TAYLOR, max_order=4)
+    z, A = simulation.run_single_simulation(cfg_m, gamma=0.0115, alpha=1.0e-4, dispersion=d, phase_matching_cfg=gen, **kw)
+    assert rel_err(A, g["gen_A"]) < RTOL_F64
+    cfg_g = config.custom_simulation_config(z_max=250.0, dz=0.25, save_every=5)
+    for tag, pm in (("sym", None), ("gen", gen)):
+        for producer in ("host", "device"):
+            out = scan_mismtach.scan_gain_grid(cfg=cfg_g, lambda_p1_m=1550e-9, lambda_p2_m=g["lambda2"],
+                                               lambda_signal_m=g["lambda3"], gamma=0.0115, alpha=1.0e-4, p_in=g["grid_p_in"],
+                                               dispersion=d, phase_matching_cfg=pm, dbeta_producer=producer)
+            assert np.max(np.abs(out["gain"] - g["grid_gain_" + tag])) < ATOL_DB, (tag, producer)
+            if tag == "sym":
+                assert np.all(np.abs(out["dbeta"] - g["grid_dbeta_sym"]) <= np.spacing(np.abs(g["grid_dbeta_sym"])))
+            else:
+                np.testing.assert_allclose(out["dbeta"], g["grid_dbeta_gen"], rtol=1e-14, atol=0)

@@ -294,3 +294,28 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(root, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "libpsa_oracle" not in src and "psa_oracle" not in src, f
+
+
+def test_g13_host_producers_against_the_reference_grid_rows(golden):
+    """The 4 x 9 (lambda_p2 x lambda_signal) grid of golden G13, which the reference produced row by row through its
+    gain + dbeta driver: the array producer must give the same dbeta for the whole grid at once -- bit-equal for the
+    symmetric closed form, within the array-pow ulp for GENERAL_TAYLOR -- and the legacy-beta defaults must reproduce the
+    reference's PROVIDED value including its km double scaling."""
+    from psa_amd.scan_mismtach import _grid_dbeta
+    g = golden("G13")
+    dv = g["disp"]
+    d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3])
+    db, ok = _grid_dbeta(1550e-9, g["lambda2"], g["lambda3"], d, PhaseMatchingConfig(), "host", 0)
+    assert ok.all() and np.array_equal(db.reshape(4, 9), g["grid_dbeta_sym"])
+    dbg, ok = _grid_dbeta(1550e-9, g["lambda2"], g["lambda3"], d, PhaseMatchingConfig(method="general_taylor", max_order=4), "host", 0)
+    assert ok.all()
+    np.testing.assert_allclose(dbg.reshape(4, 9), g["grid_dbeta_gen"], rtol=1e-14, atol=0)
+    from psa_amd import config, simulation
+    b = g["beta_legacy_m"]
+    pre = simulation._prepare(config.custom_simulation_config(z_max=200.0, dz=0.2, save_every=8), gamma=0.0115, alpha=1e-4,
+                              dispersion=None, phase_matching_cfg=None, beta_legacy=b, length_unit="m")
+    assert pre["pm"].config.provided_delta_beta == float((b[2] + b[3]) - (b[0] + b[1]))
+    pre = simulation._prepare(config.custom_simulation_config(z_max=0.2, dz=0.2e-3, save_every=8), gamma=11.5, alpha=0.1,
+                              dispersion=None, phase_matching_cfg=None, beta_legacy=b * 1e3, length_unit="km")
+    bk = (b * 1e3) / 1e3
+    assert pre["pm"].config.provided_delta_beta == float((bk[2] + bk[3]) - (bk[0] + bk[1])) / 1e3

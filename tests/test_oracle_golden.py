@@ -176,3 +176,27 @@ def test_batched_numpy_form_agrees_with_the_c_oracle(oracle):
     got = oracle.np_sweep_batched(db, z_max=50.0, n=500, gamma=0.0115, alpha=1.15e-4, a0=a0)
     ref = oracle.sweep(db, z_max=50.0, n=500, save_every=500, gamma=0.0115, alpha=1.15e-4, a0=a0)
     assert rel_err(got, ref["a_end"]) < 1e-12
+
+
+def test_g13_legacy_betas_general_taylor_and_the_grid_rows(golden, oracle):
+    """G13: paths the other fixtures do not walk.  (a) only legacy beta(w_j) given: the reference's default becomes PROVIDED
+    with dbeta = (b3 + b4) - (b1 + b2) (yaman_model.py:112) -- and in km units the legacy value is divided by the length
+    scale TWICE upstream (simulation.py: beta_legacy / scale, then the PROVIDED config / scale again), a quirk parity
+    depends on; (b) GENERAL_TAYLOR single run; (c) every row of a 4 x 9 grid through the gain + dbeta driver."""
+    g = golden("G13")
+    a0 = _a0(g["p_in"], g["phase_in"])
+    b = g["beta_legacy_m"]
+    db_m = float((b[2] + b[3]) - (b[0] + b[1]))
+    bk = (b * 1e3) / 1e3
+    db_km = float((bk[2] + bk[3]) - (bk[0] + bk[1])) / 1e3                                    # the double scaling
+    for key, db in (("legacy_m", db_m), ("legacy_km", db_km)):
+        z, A, bad = oracle.integrate(a0, z_max=200.0, n=1000, save_every=8, gamma=0.0115, alpha=1.0e-4, dbeta=db)
+        assert bad == -1 and rel_err(A, g[key + "_A"]) < TOL, key
+        np.testing.assert_allclose(z, g[key + "_z"], rtol=1e-15)
+    assert np.max(np.abs(g["legacy_km_A"][-1] - g["legacy_m_A"][-1])) > 1e-3                  # the quirk is visible
+    a_grid = _a0(g["grid_p_in"])
+    for tag in ("sym", "gen"):
+        db = g["grid_dbeta_" + tag].ravel()
+        r = oracle.sweep(db, z_max=250.0, n=1000, save_every=5, gamma=0.0115, alpha=1.0e-4, a0=a_grid)
+        gain = oracle.gain_from_summary(r["p_max"], r["first_bad_step"], g["grid_p_in"][2], "db")
+        np.testing.assert_allclose(gain, g["grid_gain_" + tag].ravel(), rtol=1e-11, atol=1e-11)

@@ -12,8 +12,9 @@
 //
 // Arithmetic follows the reference operation by operation in float64 -- this TU is compiled with -ffp-contract=off so
 // that no multiply-add pair is fused -- because dbeta feeds exp(i*dbeta*z) over ~1e5 steps.  x**n for n >= 3 is libm's
-// pow in the reference (correct to ~0.5 ulp); here it is formed in double-double and rounded once.  Result: bit-equal
-// to the NumPy path except where pow itself is not correctly rounded (<= 1 ulp of dbeta; tests/test_gpu_dbeta.py).
+// pow in the reference (correct to ~0.5 ulp); here it is formed in double-double and rounded once.  Result: bit-equal to
+// the reference on every golden vector; against NumPy's array path bit-equal on 99.8 % of a random 10^6-point grid and
+// within a few ulp (<= 2e-15 relative) where the two orders cancel (tests/test_gpu_dbeta.py, tools/dbeta_fuzz.py).
 #include <hip/hip_runtime.h>
 
 #include "psa_internal.h"

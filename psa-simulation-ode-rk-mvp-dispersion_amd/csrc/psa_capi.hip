@@ -137,6 +137,20 @@ struct DevBuf {
     template <typename U> U *as() { return (U *)p; }
 };
 
+// The dozen small per-sweep buffers of the host-buffer API come out of ONE allocation (256-B aligned slices): a single-point
+// run (BASELINE config 1) otherwise spends as long in hipMalloc / hipFree as a tenth of its kernel.
+struct DevArena {
+    DevBuf buf;
+    size_t used = 0, cap = 0;
+    static size_t aligned(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    hipError_t reserve(size_t bytes) { cap = bytes; return buf.alloc(bytes); }
+    template <typename U> U *take(size_t count) {
+        U *p = (U *)((char *)buf.p + used);
+        used += aligned(count * sizeof(U));
+        return p;
+    }
+};
+
 // Makes `device` current for the scope of a host-buffer entry point and puts the caller's device back afterwards
 // (a host-API call must not leave a side effect on a thread that also drives torch or another HIP library).
 struct DeviceScope {
@@ -202,8 +216,11 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     }
 
     DeviceScope scope;
-    DevBuf b_dbeta, b_dbeta2, b_gamma, b_alpha, b_a0_aos, b_a0_soa, b_aend_soa, b_aend_aos, b_pend, b_pmax, b_bad,
-        b_traj_soa, b_stage[2];
+    DevArena arena;
+    DevBuf b_traj_soa, b_stage[2];
+    T *d_dbeta = nullptr, *d_dbeta2 = nullptr, *d_gamma = nullptr, *d_alpha = nullptr, *d_a0_aos = nullptr, *d_a0_soa = nullptr,
+      *d_aend_soa = nullptr, *d_aend_aos = nullptr, *d_pend = nullptr, *d_pmax = nullptr;
+    int64_t *d_bad = nullptr;
     hipStream_t st = nullptr, st_copy[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_kernel = nullptr;
 
@@ -220,38 +237,45 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
         }
     }
     HIP_TRY(hipStreamCreate(&st));
-    HIP_TRY(b_dbeta.alloc(N * sizeof(T)));
-    if (dbeta2) HIP_TRY(b_dbeta2.alloc(N * sizeof(T)));
-    HIP_TRY(b_gamma.alloc(n_gamma * sizeof(T)));
-    HIP_TRY(b_alpha.alloc(n_alpha * sizeof(T)));
-    HIP_TRY(b_a0_aos.alloc(n_a0 * nc * sizeof(T)));
-    HIP_TRY(b_a0_soa.alloc(n_a0 * nc * sizeof(T)));
-    HIP_TRY(b_aend_soa.alloc(N * nc * sizeof(T)));
-    HIP_TRY(b_aend_aos.alloc(N * nc * sizeof(T)));
-    HIP_TRY(b_pend.alloc(N * sizeof(T)));
-    HIP_TRY(b_pmax.alloc(N * sizeof(T)));
-    HIP_TRY(b_bad.alloc(N * sizeof(int64_t)));
+    {
+        using A = DevArena;
+        const size_t total = A::aligned(N * sizeof(T)) * (dbeta2 ? 2 : 1) + A::aligned(n_gamma * sizeof(T)) +
+                             A::aligned(n_alpha * sizeof(T)) + 2 * A::aligned(n_a0 * nc * sizeof(T)) +
+                             2 * A::aligned(N * nc * sizeof(T)) + 2 * A::aligned(N * sizeof(T)) + A::aligned(N * sizeof(int64_t));
+        HIP_TRY(arena.reserve(total));
+        d_dbeta = arena.take<T>(N);
+        if (dbeta2) d_dbeta2 = arena.take<T>(N);
+        d_gamma = arena.take<T>(n_gamma);
+        d_alpha = arena.take<T>(n_alpha);
+        d_a0_aos = arena.take<T>(n_a0 * nc);
+        d_a0_soa = arena.take<T>(n_a0 * nc);
+        d_aend_soa = arena.take<T>(N * nc);
+        d_aend_aos = arena.take<T>(N * nc);
+        d_pend = arena.take<T>(N);
+        d_pmax = arena.take<T>(N);
+        d_bad = arena.take<int64_t>(N);
+    }
     if (traj) HIP_TRY(b_traj_soa.alloc(traj_elems * sizeof(T)));
-    HIP_TRY(hipMemcpyAsync(b_dbeta.p, dbeta, N * sizeof(T), hipMemcpyHostToDevice, st));
-    if (dbeta2) HIP_TRY(hipMemcpyAsync(b_dbeta2.p, dbeta2, N * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_gamma.p, gamma, n_gamma * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_alpha.p, alpha, n_alpha * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_a0_aos.p, a0, n_a0 * nc * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(Launch<T>::a2s(st, b_a0_aos.as<T>(), b_a0_soa.as<T>(), (long long)n_a0, nc));
+    HIP_TRY(hipMemcpyAsync(d_dbeta, dbeta, N * sizeof(T), hipMemcpyHostToDevice, st));
+    if (dbeta2) HIP_TRY(hipMemcpyAsync(d_dbeta2, dbeta2, N * sizeof(T), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_gamma, gamma, n_gamma * sizeof(T), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_alpha, alpha, n_alpha * sizeof(T), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_a0_aos, a0, n_a0 * nc * sizeof(T), hipMemcpyHostToDevice, st));
+    HIP_TRY(Launch<T>::a2s(st, d_a0_aos, d_a0_soa, (long long)n_a0, nc));
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, st));
-    rc = sweep_dev<T>(st, n_waves, n_points, n_steps, z_max, save_every, b_dbeta.as<T>(),
-                      dbeta2 ? b_dbeta2.as<T>() : nullptr, b_gamma.as<T>(), b_alpha.as<T>(), b_a0_soa.as<T>(), flags,
-                      b_aend_soa.as<T>(), b_pend.as<T>(), b_pmax.as<T>(), b_bad.as<int64_t>(),
+    rc = sweep_dev<T>(st, n_waves, n_points, n_steps, z_max, save_every, d_dbeta,
+                      d_dbeta2, d_gamma, d_alpha, d_a0_soa, flags,
+                      d_aend_soa, d_pend, d_pmax, d_bad,
                       traj ? b_traj_soa.as<T>() : nullptr);
     if (rc != PSA_OK) goto done;
     HIP_TRY(hipEventRecord(ev1, st));
-    HIP_TRY(Launch<T>::s2a(st, b_aend_soa.as<T>(), b_aend_aos.as<T>(), (long long)N, nc));
-    HIP_TRY(hipMemcpyAsync(a_end, b_aend_aos.p, N * nc * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p_end, b_pend.p, N * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p_max, b_pmax.p, N * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(first_bad, b_bad.p, N * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(Launch<T>::s2a(st, d_aend_soa, d_aend_aos, (long long)N, nc));
+    HIP_TRY(hipMemcpyAsync(a_end, d_aend_aos, N * nc * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p_end, d_pend, N * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p_max, d_pmax, N * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(first_bad, d_bad, N * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     if (traj && N == 1) {   // [rows][nw][1] and [1][rows][nw] coincide
         HIP_TRY(hipMemcpyAsync(traj, b_traj_soa.p, traj_elems * sizeof(T), hipMemcpyDeviceToHost, st));
     } else if (traj) {

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Developer soak: the randomized differential test of tests/test_gpu_parity.py with many more cases and wider ranges
+(float64 both lane layouts, float32 packed / scalar, 4 / 6 waves, trajectories, failing points, every check mode) against
+the oracle.  Usage: python tools/soak_differential.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import psa_amd._native as nat
+import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+strides = [1, 2, 3, 7, 10, 31, 32, 33, 63, 64, 65, 100, 257, 1000]
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    fin = np.isfinite(b)
+    if not np.array_equal(np.isfinite(a), fin):
+        return np.inf
+    return float(np.max(np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-300))) if fin.any() else 0.0
+
+
+t0 = time.time()
+case = fails = 0
+worst = {"f64": 0.0, "f32": 0.0}
+stop_at = int(os.environ.get("SOAK_DETAIL", "0"))
+while time.time() - t0 < budget and not (stop_at and case >= stop_at):
+    case += 1
+    N = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 3000))]))
+    n = int(rng.integers(1, 3000))
+    se = int(rng.choice(strides))
+    nw = int(rng.choice([4, 6]))
+    f32 = bool(rng.integers(0, 4) == 0)
+    check, exact = bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 2))
+    traj = bool(rng.integers(0, 3) == 0) and (n // se + 1) * N < 200_000
+    L = float(rng.uniform(5.0, 120.0))
+    db = rng.uniform(-0.2, 0.2, N)
+    db2 = rng.uniform(-0.2, 0.2, N) if nw == 6 else None
+    gamma = rng.uniform(5e-3, 2e-2, N) if rng.integers(0, 2) else float(rng.uniform(5e-3, 2e-2))
+    hot = -1
+    if rng.integers(0, 5) == 0 and not f32:            # a few blow-ups: first_bad_step must match exactly / per block
+        gamma = np.broadcast_to(np.asarray(gamma, dtype=float), (N,)).copy()
+        hot = int(rng.integers(0, N))
+        gamma[hot] = float(rng.uniform(30.0, 300.0))
+    alpha = rng.uniform(0, 3e-4, N) if rng.integers(0, 2) else float(rng.choice([0.0, 1.15e-4]))
+    amp = np.sqrt(rng.uniform(1e-6, 0.8, (N, nw))) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, nw)))
+    a0 = amp if rng.integers(0, 2) else amp[0]
+    flags = int(rng.choice([0, nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, nat.OPT_BLOCK64]))
+    if f32:
+        flags = int(rng.choice([0, nat.OPT_F32_SCALAR, nat.OPT_F32_PACKED]))
+        db, db2 = db.astype(np.float32), (None if db2 is None else db2.astype(np.float32))
+    tag = f"case {case}: N={N} n={n} se={se} nw={nw} f32={f32} check={check} exact={exact} traj={traj} flags={flags:#x} L={L:.3f}"
+    ref = O.sweep(np.asarray(db, float), z_max=L, n=n, save_every=se, check_nan=check, gamma=gamma, alpha=alpha, a0=a0,
+                  dbeta2=(None if db2 is None else np.asarray(db2, float)))
+    got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2, check_nan=check,
+                         exact_step=exact, want_traj=traj, extra_flags=flags, dtype=(np.float32 if f32 else np.float64))
+    ok_pts = ref["first_bad_step"] < 0
+    if hot >= 0:   # a hot point that happens to stay finite carries hundreds of radians of nonlinear phase: chaotic, any two
+        ok_pts = ok_pts.copy()          # correctly rounded implementations differ by O(1) there (one-lane vs two-lane vs oracle)
+        ok_pts[hot] = False
+    tol = 2e-3 if f32 else 1e-9
+    errs = [rel(got["a_end"][ok_pts].astype(complex), ref["a_end"][ok_pts]), rel(got["p_max"][ok_pts].astype(float), ref["p_max"][ok_pts])]
+    bad_ok = True
+    if check and not f32:
+        if exact:
+            bad_ok = np.array_equal(got["first_bad_step"], ref["first_bad_step"])
+        else:
+            bad_ok = np.array_equal(got["first_bad_step"] >= 0, ref["first_bad_step"] >= 0)
+    if traj and ok_pts.any():
+        i = int(np.flatnonzero(ok_pts)[0])
+        g_i = gamma[i] if np.ndim(gamma) else gamma
+        al_i = alpha[i] if np.ndim(alpha) else alpha
+        a_i = a0[i] if a0.ndim == 2 else a0
+        z, A, _ = O.integrate(a_i, z_max=L, n=n, save_every=se, check_nan=check, gamma=g_i, alpha=al_i, dbeta=float(db[i]),
+                              dbeta2=(float(db2[i]) if nw == 6 else 0.0))
+        errs.append(rel(got["traj"][i].astype(complex), A))
+    e = max(errs)
+    worst["f32" if f32 else "f64"] = max(worst["f32" if f32 else "f64"], e if np.isfinite(e) else 0.0)
+    if case == int(os.environ.get("SOAK_DETAIL", "-1")) or not (e < tol and bad_ok):
+        d = np.abs(got["a_end"].astype(complex) - ref["a_end"]) / np.maximum(np.abs(ref["a_end"]), 1e-300)
+        d[~ok_pts] = 0
+        i, j = np.unravel_index(np.argmax(d), d.shape)
+        print(f"DETAIL {tag}: worst a_end element point {i} wave {j}: got {got['a_end'][i, j]!r} ref {ref['a_end'][i, j]!r}; "
+              f"|A| of that point: {np.abs(ref['a_end'][i])}; abs err / max|A| = {np.abs(got['a_end'][i, j] - ref['a_end'][i, j]) / np.abs(ref['a_end'][i]).max():.3e}", flush=True)
+        g_i = gamma[i] if np.ndim(gamma) else gamma
+        print(f"   gamma of that point {g_i}, nonlinear phase gamma*P*L ~ {g_i * (np.abs(ref['a_end'][i]) ** 2).sum() * L:.1f} rad", flush=True)
+        if not f32:
+            for nm, fl in (("one lane", nat.OPT_ONE_LANE), ("two lanes", nat.OPT_SPLIT_POINT)):
+                alt = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2,
+                                     check_nan=check, exact_step=exact, extra_flags=fl)
+                print(f"   {nm}: a_end[{i}] vs oracle {np.abs(alt['a_end'][i] - ref['a_end'][i]).max():.3e}, vs first run {np.abs(alt['a_end'][i] - got['a_end'][i]).max():.3e}", flush=True)
+    if not (e < tol and bad_ok):
+        fails += 1
+        print("FAIL", tag, "errs", errs, "bad_ok", bad_ok, "got_bad", got["first_bad_step"][:8], "ref_bad", ref["first_bad_step"][:8], flush=True)
+    if case % 200 == 0:
+        print(f"{case} cases, {fails} failures, worst f64 {worst['f64']:.2e} f32 {worst['f32']:.2e}, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {case} cases, {fails} failures, worst f64 {worst['f64']:.2e}, worst f32 {worst['f32']:.2e}")
+sys.exit(1 if fails else 0)

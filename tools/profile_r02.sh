@@ -18,12 +18,12 @@ for cfg in "$@"; do
     traj)  ARGS="--mode trajectory --steps 5 --warmup 1" ;;
   esac
   echo "== $cfg: stats"
-  rocprofv3 --kernel-trace --stats -d $OUT/${cfg}_stats -- python3 bench.py $ARGS > $OUT/${cfg}_stats.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${cfg}_stats -- python3 bench.py $ARGS > $OUT/${cfg}_stats.log 2>&1
   for grp in "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES" \
              "grbm:GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
     name=${grp%%:*}; ctrs=${grp#*:}
     echo "== $cfg: pmc $name"
-    rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/${cfg}_pmc_$name -- python3 bench.py $ARGS > $OUT/${cfg}_pmc_$name.log 2>&1
+    rocprofv3 --kernel-trace --output-format csv --pmc $ctrs -d $OUT/${cfg}_pmc_$name -- python3 bench.py $ARGS > $OUT/${cfg}_pmc_$name.log 2>&1
   done
 done
 echo done

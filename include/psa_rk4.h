@@ -102,7 +102,10 @@ int64_t     psa_n_saved(int64_t n_steps, int32_t save_every);   /* n_steps / sav
  *   p_sig_end  [N]   |A_sig|^2 at that row            (gain_mode "end", scan_mismtach.py:36-37)
  *   p_sig_max  [N]   max over saved rows incl. z = 0  (gain_mode "max", :38-39; NaN-propagating like np.max)
  *   first_bad_step [N]  -1, or the 0-based step index after which the state was non-finite
- *   traj_or_null   [N][n_saved][n_waves][2]  every saved row (integrators.py:137-140), or NULL
+ *   traj_or_null   [N][n_saved][n_waves][2]  every saved row (integrators.py:137-140), or NULL.  A launch with a
+ *                  trajectory takes at most 2^28 - 1 points in float64 (2^29 - 1 in float32: rows are addressed with a
+ *                  32-bit lane offset) and must fit the device's free memory, else PSA_E_TOO_LARGE; the host-buffer
+ *                  variant moves it to the host in bounded chunks (two 256 MB staging buffers)
  *   elapsed_ms_or_null  kernel time from hipEvents on the launch stream, or NULL
  */
 int psa_rk4_sweep_f64(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max,

@@ -253,8 +253,9 @@ def trajectory_mode(args, dev, saved_stdout_fd) -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed passes (default 10; 100 in trajectory mode)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed passes first (default 2; 30 in trajectory mode, "
+                                                             "where the first ~20 launches run at a clock still ramping)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE configuration per GPU (default c2 = the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the ~15 s CPU leg (profiling runs)")
@@ -266,6 +267,10 @@ def main() -> None:
                          "an HBM roofline object.  Not the headline metric.")
     ap.add_argument("--exact-step", action="store_true", help="per-step finite test instead of per save block")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if args.mode == "trajectory" else 10
+    if args.warmup is None:
+        args.warmup = 30 if args.mode == "trajectory" else 2
     cfg = CONFIGS[args.config]
     nw, n_z, pts = cfg["n_waves"], cfg["n_steps"], cfg["pts_per_gpu"]
 

@@ -28,3 +28,19 @@ for name, cfg in (("symmetric (2,4)", PhaseMatchingConfig()), ("symmetric (2,)",
     rel = np.abs(dev[good] - ref[good]) / np.abs(ref[good])
     print(f"{name:18s}: {good.sum()} valid points, bit-equal {np.mean(u == 0) * 100:.3f} %, <= 1 ulp {np.mean(u <= 1) * 100:.4f} %, "
           f"max {u.max():.1f} ulp, max rel {rel.max():.2e}", flush=True)
+
+# ---- validity: wavelengths far outside the band, so that a large fraction of the plans is impossible (omega_4 <= 0,
+# |omega_d| >= omega_c, energy conservation, non-finite dbeta); the device mask must equal the host mask exactly
+lam2w = np.concatenate([np.sort(rng.uniform(0.4e-6, 4e-6, 996)), [0.0, -1e-6, np.nan, np.inf]])
+lam3w = np.concatenate([np.sort(rng.uniform(0.3e-6, 6e-6, 997)), [0.0, -2e-6, np.nan]])
+L2, L3 = np.meshgrid(lam2w, lam3w, indexing="ij")
+with np.errstate(all="ignore"):
+    om, ok = frequency_plan.plan_from_wavelengths_batch(1550e-9, L2.ravel(), L3.ravel())
+    for name, cfg in (("symmetric (2,4)", PhaseMatchingConfig()), ("taylor 4", PhaseMatchingConfig(method="general_taylor", max_order=4))):
+        ref, ok2 = phase_matching.compute_phase_mismatch_batch(om, d, cfg)
+        dev, okd = nat.dbeta_grid_host(nat.dbeta_model(d, cfg), 1550e-9, lam2w, lam3w)
+        good = ok & ok2
+        same = np.array_equal(okd, good)
+        nan_ok = np.array_equal(np.isnan(dev), ~good)
+        print(f"validity {name:16s}: {good.sum()} valid of {good.size}, masks equal: {same}, NaN exactly where invalid: {nan_ok}", flush=True)
+        assert same and nan_ok

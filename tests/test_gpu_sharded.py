@@ -255,3 +255,36 @@ def test_three_ranks_generate_their_blocks_and_gather_ragged_records(tmp_path, o
     assert rel_err(r[0]["pm_f64"], ref["p_max"]) < RTOL_F64 and (r[0]["fb_f64"] == -1).all()
     ref32 = oracle.sweep(r[0]["db_f32"].astype(np.float64), z_max=200.0, n=2000, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=a0)
     assert r[0]["a_f32"].dtype == np.complex64 and rel_err(r[0]["a_f32"].astype(complex), ref32["a_end"]) < RTOL_F32
+
+
+def test_six_wave_float32_shard_with_device_generated_pairs(oracle):
+    """The one combination the BASELINE configurations do not use -- six waves in float32 (packed kernel, 64 B/point record,
+    psa_dbeta_pairs_f32_dev) -- through the same shard object, against the float64 oracle."""
+    import torch
+    from psa_amd import dispersion, frequency_plan
+    from psa_amd.distributed import DeviceSweep
+    d = dispersion.dispersion_params_from_D_S(1554e-9, 0.1, 0.02, 0.0, D_units="ps/nm/km", S_units="ps/nm^2/km",
+                                              dSdlmbd_units="ps/nm^3/km")
+    w1, w2 = frequency_plan.omega_from_lambda(1550e-9), frequency_plan.omega_from_lambda(1558e-9)
+    wd = 0.5 * (w1 - w2)
+    O1, O2 = np.linspace(2e12, 2.4e13, 13), np.linspace(3e12, 2.0e13, 17)
+    n = O1.size * O2.size                                             # 221: odd, so the last packed lane is half filled
+    ds = DeviceSweep(n_local=n, n_steps=3000, z_max=300.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A6, dtype=np.float32)
+    ds.fill_dbeta_pairs(nat.dbeta_model(d, None, even_orders=(2, 4)), wd, O1, O2, first=0)
+    ds.launch()
+    ds.summarize(float(P6[2]), mode="max", gain_db=True)
+    torch.cuda.synchronize()
+    assert ds.record.numel() * 8 == 64 * n
+    db1, db2 = ds.dbeta.cpu().numpy(), ds.dbeta2.cpu().numpy()
+    r1 = dispersion.delta_beta_symmetric_array(wd, O1, d)
+    r2 = dispersion.delta_beta_symmetric_array(wd, O2, d)
+    R1, R2 = (m.ravel() for m in np.meshgrid(r1, r2, indexing="ij"))
+    assert db1.dtype == np.float32 and np.array_equal(db1, R1.astype(np.float32)) and np.array_equal(db2, R2.astype(np.float32))
+    ref = oracle.sweep(db1.astype(np.float64), dbeta2=db2.astype(np.float64), z_max=300.0, n=3000, save_every=10, gamma=0.0115,
+                       alpha=1.15e-4, a0=A6)
+    res = ds.result()
+    assert res.a_end.dtype == np.complex64 and res.a_end.shape == (n, 6) and (res.first_bad_step == -1).all()
+    scale = np.abs(ref["a_end"]).max(axis=1, keepdims=True)          # float32: error relative to the point's largest wave
+    assert np.max(np.abs(res.a_end.astype(complex) - ref["a_end"]) / scale) < RTOL_F32
+    want = oracle.gain_from_summary(ref["p_max"], ref["first_bad_step"], P6[2], "db")
+    assert np.max(np.abs(ds.gain.cpu().numpy().astype(float) - want)) < 2e-3

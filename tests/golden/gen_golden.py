@@ -21,6 +21,8 @@ Fixture ids follow SURVEY.md section 8(c):
   G10 dbeta producer cases (unit variants, GENERAL_TAYLOR, dS/dlambda != 0 quirk)
   G11 driver variants: km units, linear gain, non-zero input phases
   G12 a run bundle written by the reference's io_fwm (npz + csv + json): pins the file format
+  API api_signatures.json: parameter names / kinds / defaults of every public function and the field names of every public
+      dataclass of the hot-path modules (the drop-in boundary as data)
   G13 paths the other fixtures do not walk: legacy beta(w_j) fallback (m and km), GENERAL_TAYLOR through the single run and
       through the gain+dbeta driver, and a 4 x 9 (lambda_p2 x lambda_signal) grid run row by row through the reference's
       driver (pins the build's 2-D grid scan and its device-side dbeta producer against the reference itself)
@@ -416,6 +418,34 @@ def gen_g13(pool):
           grid_gain_gen=np.array([r[0] for r in rows_gen]), grid_dbeta_gen=np.array([r[1] for r in rows_gen]))
 
 
+def gen_api_signatures():
+    """The call surface of the hot-path modules as data: for every public function its parameter names, kinds and
+    defaults (as repr), for every public dataclass its field names.  Pins the drop-in boundary."""
+    import dataclasses
+    import importlib
+    import inspect
+    import json
+    out = {}
+    for modname in ("config", "integrators", "simulation", "scan_mismtach", "yaman_model", "parameters", "frequency_plan",
+                    "dispersion", "phase_matching", "io_fwm"):
+        m = importlib.import_module(modname)
+        entry = {}
+        for k, v in vars(m).items():
+            if k.startswith("_") or not callable(v) or getattr(v, "__module__", "") != m.__name__:
+                continue
+            if inspect.isclass(v):
+                entry[k] = {"kind": "class", "fields": [f.name for f in dataclasses.fields(v)] if dataclasses.is_dataclass(v) else None}
+            else:
+                entry[k] = {"kind": "function",
+                            "params": [[n, q.kind.name, repr(q.default) if q.default is not inspect._empty else "<required>"]
+                                       for n, q in inspect.signature(v).parameters.items()]}
+        out[modname] = entry
+    path = os.path.join(HERE, "api_signatures.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"  wrote api_signatures.json ({os.path.getsize(path)} B)", flush=True)
+
+
 def gen_g12():
     """Files written by the reference's io_fwm.save_run_bundle (tiny: 6 rows) -- pins the on-disk format."""
     import io_fwm
@@ -438,7 +468,7 @@ def main() -> None:
     with Pool(args.procs) as pool:
         for gid, fn, needs_pool in [("G1", gen_g1, False), ("G4", gen_g4, False), ("G5", gen_g5, False),
                                     ("G6", gen_g6, False), ("G7", gen_g7, False), ("G9", gen_g9, False),
-                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
+                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("API", gen_api_signatures, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
                                     ("G11", gen_g11, True), ("G8", gen_g8, True)]:
             if want(gid):
                 print(f"{gid} ... ({time.perf_counter() - t0:.0f}s)", flush=True)

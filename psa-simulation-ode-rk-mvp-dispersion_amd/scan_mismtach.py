@@ -177,6 +177,7 @@ def plot_max_signal_gain_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m:
     ys = _norm_choice(yscale, "yscale", ("linear", "log"))
     if ys == "log" and unit == "db":
         raise ValueError("yscale='log' is not supported with gain_unit='dB'. Use gain_unit='linear'.")
+    _wavelength_axis(lam3, return_wavelength_unit)   # the reference raises this only AFTER its sweep; here before any device work
 
     gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
                              dispersion=dispersion, pm_cfg=phase_matching_cfg, length_unit=length_unit,
@@ -227,6 +228,7 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
         raise ValueError("yscale_gain='log' is not supported with gain_unit='dB'. Use gain_unit='linear'.")
     pm_cfg = phase_matching_cfg if phase_matching_cfg is not None else PhaseMatchingConfig(
         method=PhaseMatchingMethod.SYMMETRIC_EVEN, max_order=4, even_orders=(2, 4), atol=0.0, rtol=1e-12)
+    _wavelength_axis(lam3, return_wavelength_unit)   # validated up front (upstream: after the sweep)
 
     # dbeta in the caller's units: per point, NaN where the plan or the mismatch is invalid
     try:

@@ -352,3 +352,28 @@ def test_public_call_surface_equals_the_reference(golden):
                 assert got[:len(want["params"])] == want["params"], f"{modname}.{name}: {got} != {want['params']}"
             checked += 1
     assert checked >= 55
+
+
+def test_error_contract_equals_the_reference():
+    """tests/golden/error_contract.json records what the REFERENCE raises (exception type, message) for the 44 invalid calls
+    of tests/golden/error_cases.py; the package must raise the same exception TYPE for every one of them (or, like the
+    reference, nothing), and it must do so in argument validation -- this test runs without a GPU.  Messages are free to
+    differ in wording; where they are identical is reported."""
+    import importlib
+    import json
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, here)
+    try:
+        import error_cases
+    finally:
+        sys.path.remove(here)
+    want = json.load(open(os.path.join(here, "error_contract.json")))
+    got = error_cases.evaluate(lambda m: importlib.import_module("psa_amd." + m))
+    assert set(got) == set(want) and len(want) >= 44
+    wrong = {k: (want[k], got[k]) for k in want if want[k][0] != got[k][0]}
+    assert not wrong, wrong
+    same_text = sum(want[k][1] == got[k][1] for k in want)
+    print(f"{len(want)} invalid calls: same exception type in all, identical message in {same_text}")
+    assert same_text >= 30

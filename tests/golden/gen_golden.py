@@ -24,6 +24,8 @@ Fixture ids follow SURVEY.md section 8(c):
   API api_signatures.json: parameter names / kinds / defaults of every public function and the field names of every public
       dataclass of the hot-path modules (the drop-in boundary as data)
   ERR error_contract.json: exception type + message the reference raises for the invalid calls listed in error_cases.py
+  HOST host_api_records.json.gz: every return value (or exception type) of the scalar host API along the seeded random walk
+      of host_api_cases.py (300 plans x dispersion builders x phase-matching methods, 40 configurations)
   G13 paths the other fixtures do not walk: legacy beta(w_j) fallback (m and km), GENERAL_TAYLOR through the single run and
       through the gain+dbeta driver, and a 4 x 9 (lambda_p2 x lambda_signal) grid run row by row through the reference's
       driver (pins the build's 2-D grid scan and its device-side dbeta producer against the reference itself)
@@ -460,6 +462,20 @@ def gen_error_contract():
     print(f"  wrote error_contract.json ({len(out)} cases, {os.path.getsize(path)} B)", flush=True)
 
 
+def gen_host_api_records():
+    """What the reference returns (or raises) along the seeded random walk of tests/golden/host_api_cases.py."""
+    import gzip
+    import importlib
+    import json
+    sys.path.insert(0, HERE)
+    import host_api_cases
+    out = host_api_cases.evaluate(importlib.import_module)
+    path = os.path.join(HERE, "host_api_records.json.gz")
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        json.dump(out, f, sort_keys=True)
+    print(f"  wrote host_api_records.json.gz ({len(out)} records, {os.path.getsize(path)} B)", flush=True)
+
+
 def gen_g12():
     """Files written by the reference's io_fwm.save_run_bundle (tiny: 6 rows) -- pins the on-disk format."""
     import io_fwm
@@ -482,7 +498,7 @@ def main() -> None:
     with Pool(args.procs) as pool:
         for gid, fn, needs_pool in [("G1", gen_g1, False), ("G4", gen_g4, False), ("G5", gen_g5, False),
                                     ("G6", gen_g6, False), ("G7", gen_g7, False), ("G9", gen_g9, False),
-                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("API", gen_api_signatures, False), ("ERR", gen_error_contract, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
+                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("API", gen_api_signatures, False), ("ERR", gen_error_contract, False), ("HOST", gen_host_api_records, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
                                     ("G11", gen_g11, True), ("G8", gen_g8, True)]:
             if want(gid):
                 print(f"{gid} ... ({time.perf_counter() - t0:.0f}s)", flush=True)

@@ -377,3 +377,28 @@ def test_error_contract_equals_the_reference():
     same_text = sum(want[k][1] == got[k][1] for k in want)
     print(f"{len(want)} invalid calls: same exception type in all, identical message in {same_text}")
     assert same_text >= 30
+
+
+def test_scalar_host_api_is_bit_identical_to_the_reference_along_a_random_walk():
+    """tests/golden/host_api_records.json.gz: ~1 850 return values the REFERENCE produced along the seeded walk of
+    host_api_cases.py -- frequency plans (every 7th without an idler: exception types recorded), symmetric decompositions,
+    describe_plan text, dispersion builders incl. the dS/dlambda slot quirk, Taylor and symmetric mismatch in several orders,
+    every phase-matching method, configuration objects.  The package must reproduce every record exactly (floats bit for bit)."""
+    import gzip
+    import importlib
+    import json
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, here)
+    try:
+        import host_api_cases
+    finally:
+        sys.path.remove(here)
+    with gzip.open(os.path.join(here, "host_api_records.json.gz"), "rt", encoding="utf-8") as f:
+        want = json.load(f)
+    got = json.loads(json.dumps(host_api_cases.evaluate(lambda m: importlib.import_module("psa_amd." + m))))
+    assert set(got) == set(want) and len(want) > 1800
+    wrong = [k for k in want if want[k] != got[k]]
+    assert not wrong, (wrong[:5], want[wrong[0]], got[wrong[0]])
+    assert sum(1 for v in want.values() if isinstance(v, list) and v and v[0] == "EXC") > 50

@@ -9,7 +9,7 @@ import numpy as np
 
 
 def evaluate(imp):
-    fp, dp, pm, config = (imp(m) for m in ("frequency_plan", "dispersion", "phase_matching", "config"))
+    fp, dp, pm, config, prm = (imp(m) for m in ("frequency_plan", "dispersion", "phase_matching", "config", "parameters"))
     rng = np.random.default_rng(99)
     out = {}
 
@@ -66,6 +66,67 @@ def evaluate(imp):
             config.validate_config(c)
             return [c.z_max, c.dz, c.save_every, c.check_nan]
         tryrec(f"config{i}", cfg)
+    # the parameter carriers (parameters.py): valid and invalid constructions, the cache setter, the default factories
+    disp = dp.DispersionParams(omega_ref=1.2e15, beta2=-2e-28, beta4=1e-55)
+    om_ok = fp.plan_from_wavelengths(1550e-9, 1558e-9, 1554e-9)
+    carriers = {
+        "fiber.ok": lambda: prm.FiberParams(length_m=100.0, gamma_W_m=0.01, alpha_1_m=1e-4, dispersion=disp, beta_legacy_1_m=None),
+        "fiber.legacy": lambda: prm.FiberParams(length_m=100.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion=None,
+                                               beta_legacy_1_m=np.array([1.0, 2.0, 3.0, 4.0])),
+        "fiber.length<=0": lambda: prm.FiberParams(length_m=0.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion=None, beta_legacy_1_m=None),
+        "fiber.alpha<0": lambda: prm.FiberParams(length_m=1.0, gamma_W_m=0.01, alpha_1_m=-1.0, dispersion=None, beta_legacy_1_m=None),
+        "fiber.gamma_nan": lambda: prm.FiberParams(length_m=1.0, gamma_W_m=float("nan"), alpha_1_m=0.0, dispersion=None, beta_legacy_1_m=None),
+        "fiber.disp_type": lambda: prm.FiberParams(length_m=1.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion={"b": 1}, beta_legacy_1_m=None),
+        "fiber.legacy_shape": lambda: prm.FiberParams(length_m=1.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion=None, beta_legacy_1_m=[1.0, 2.0]),
+        "waves.ok": lambda: prm.WavesParams(omega=om_ok, symmetric=None),
+        "waves.shape": lambda: prm.WavesParams(omega=[1e15, 1e15], symmetric=None),
+        "waves.nonpos": lambda: prm.WavesParams(omega=[1e15, 1e15, 0.0, 1e15], symmetric=None),
+        "waves.sym_type": lambda: prm.WavesParams(omega=om_ok, symmetric=(1.0, 2.0, 3.0)),
+        "grid.ok": lambda: prm.SimulationGrid(dz_m=0.1, z0_m=0.0),
+        "grid.dz<=0": lambda: prm.SimulationGrid(dz_m=0.0, z0_m=0.0),
+        "grid.z0_nan": lambda: prm.SimulationGrid(dz_m=0.1, z0_m=float("nan")),
+        "pmparams.type": lambda: prm.PhaseMatchingParams(config="symmetric_even"),
+        "pmparams.default": lambda: prm.make_default_phase_matching_params(),
+        "pmparams.general": lambda: prm.make_default_phase_matching_params(method=pm.PhaseMatchingMethod.GENERAL_TAYLOR),
+        "model.cache_type": lambda: prm.ModelParams(waves=prm.WavesParams(omega=om_ok, symmetric=None),
+                                                    fiber=prm.FiberParams(length_m=1.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion=None, beta_legacy_1_m=None),
+                                                    grid=prm.SimulationGrid(dz_m=0.1, z0_m=0.0),
+                                                    phase_matching=prm.make_default_phase_matching_params(), cache={}),
+    }
+
+    def show(obj):
+        """A JSON view of a carrier: its field values (arrays as lists, nested carriers recursively, enums by value)."""
+        import dataclasses
+        import enum
+        if dataclasses.is_dataclass(obj) and not isinstance(obj, type):
+            return {f.name: show(getattr(obj, f.name)) for f in dataclasses.fields(obj)}
+        if isinstance(obj, np.ndarray):
+            return obj.tolist()
+        if isinstance(obj, enum.Enum):
+            return obj.value
+        if isinstance(obj, (tuple, list)):
+            return [show(x) for x in obj]
+        if isinstance(obj, dict):
+            return {str(k): show(v) for k, v in obj.items()}
+        return obj
+
+    for name, fn in carriers.items():
+        tryrec("carrier." + name, lambda fn=fn: show(fn()))
+
+    def model_and_cache():
+        mp = prm.make_model_params(waves=prm.WavesParams(omega=om_ok, symmetric=None),
+                                   fiber=prm.FiberParams(length_m=50.0, gamma_W_m=0.01, alpha_1_m=0.0, dispersion=disp, beta_legacy_1_m=None),
+                                   grid=prm.SimulationGrid(dz_m=0.1, z0_m=0.0))
+        before = show(mp)
+        mp.cache.set_phase_mismatch(0.125)
+        res = [before, mp.cache.delta_beta_1_m]
+        try:
+            mp.cache.set_phase_mismatch(float("nan"))
+            res.append("accepted")
+        except Exception as e:   # noqa: BLE001
+            res.append(["EXC", type(e).__name__])
+        return res
+    tryrec("carrier.model_and_cache", model_and_cache)
     d0 = config.default_simulation_config()
     rec("default_config", [d0.z_max, d0.dz, d0.save_every, d0.check_nan])
     return out

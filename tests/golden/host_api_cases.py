@@ -9,7 +9,8 @@ import numpy as np
 
 
 def evaluate(imp):
-    fp, dp, pm, config, prm = (imp(m) for m in ("frequency_plan", "dispersion", "phase_matching", "config", "parameters"))
+    fp, dp, pm, config, prm, integ = (imp(m) for m in ("frequency_plan", "dispersion", "phase_matching", "config", "parameters",
+                                                      "integrators"))
     rng = np.random.default_rng(99)
     out = {}
 
@@ -127,6 +128,41 @@ def evaluate(imp):
             res.append(["EXC", type(e).__name__])
         return res
     tryrec("carrier.model_and_cache", model_and_cache)
+    # the generic stepper with arbitrary Python callables (integrators.py:25-204): real and complex linear systems with a
+    # z-dependent coefficient, random grids and save strides; complex results are recorded as interleaved (re, im) floats
+    def flat(y):
+        y = np.asarray(y)
+        return y.view(np.float64).tolist() if np.iscomplexobj(y) else y.tolist()
+
+    for i in range(24):
+        dim = int(rng.integers(1, 6))
+        M = rng.normal(size=(dim, dim)) + 1j * rng.normal(size=(dim, dim)) * (i % 2)
+
+        def f(z, y, p, M=M):
+            return M @ y * np.cos(z) - 0.1 * y
+        y0 = rng.normal(size=dim) + (1j * rng.normal(size=dim) if i % 2 else 0)
+        zmax, dz, se = float(rng.uniform(0.1, 3.0)), float(rng.uniform(0.01, 0.3)), int(rng.integers(1, 6))
+        z_step = float(rng.uniform(0, 1))
+        zg = np.sort(rng.uniform(0, 2, int(rng.integers(2, 12))))
+
+        def interval():
+            z, y = integ.integrate_interval(f, zmax, dz, y0, None, save_every=se, check_nan=bool(i % 3))
+            return [z.tolist(), flat(y), str(y.dtype), list(y.shape)]
+
+        def fixed():
+            z, y = integ.integrate_fixed_step(f, zg, y0, None, save_every=se)
+            return [z.tolist(), flat(y)]
+        tryrec(f"stepper.interval{i}", interval)
+        tryrec(f"stepper.rk4_step{i}", lambda: flat(integ.rk4_step(f, z_step, y0, dz, None)))
+        tryrec(f"stepper.fixed{i}", fixed)
+
+    def blow_up():
+        try:
+            integ.integrate_interval(lambda z, y, p: y * y * 1e6, 10.0, 0.5, np.array([10.0]), None)
+            return "no exception"
+        except FloatingPointError as e:
+            return ["FloatingPointError", str(e)]
+    tryrec("stepper.blow_up", blow_up)
     d0 = config.default_simulation_config()
     rec("default_config", [d0.z_max, d0.dz, d0.save_every, d0.check_nan])
     return out

@@ -23,6 +23,7 @@ Fixture ids follow SURVEY.md section 8(c):
   G12 a run bundle written by the reference's io_fwm (npz + csv + json): pins the file format
   API api_signatures.json: parameter names / kinds / defaults of every public function and the field names of every public
       dataclass of the hot-path modules (the drop-in boundary as data)
+  G15 SURVEY 8(d)'s robustness draw through the reference: 32 single runs with every physical and numerical parameter random
   ERR error_contract.json: exception type + message the reference raises for the invalid calls listed in error_cases.py
   HOST host_api_records.json.gz: every return value (or exception type) of the scalar host API along the seeded random walk
       of host_api_cases.py (300 plans x dispersion builders x phase-matching methods, 40 configurations)
@@ -476,6 +477,44 @@ def gen_host_api_records():
     print(f"  wrote host_api_records.json.gz ({len(out)} records, {os.path.getsize(path)} B)", flush=True)
 
 
+def _g15_run(args):
+    import config, simulation
+    from phase_matching import PhaseMatchingConfig, PhaseMatchingMethod
+    (L, n, se, gamma, alpha, db, p_in, phase) = args
+    cfg = config.custom_simulation_config(z_max=L, dz=L / n, save_every=se)
+    pm = PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, provided_delta_beta=db)
+    z, A = simulation.run_single_simulation(cfg, gamma=gamma, alpha=alpha, omega=np.full(4, 1.2e15), p_in=p_in, phase_in=phase,
+                                            phase_matching_cfg=pm)
+    return z, A
+
+
+def gen_g15(pool):
+    """SURVEY 8(d)'s robustness draw run through the REFERENCE: 32 single runs with dbeta, gamma, alpha, all four powers and
+    phases, fibre length, step count and save stride drawn from default_rng(2026)."""
+    rng = np.random.default_rng(2026)
+    N = 32
+    L = rng.uniform(50.0, 400.0, N)
+    n = rng.integers(500, 3000, N)
+    se = rng.choice([1, 3, 10, 32, 64, 100], N)
+    gamma = rng.uniform(5e-3, 2e-2, N)
+    alpha = rng.uniform(0.0, 3e-4, N)
+    alpha[::5] = 0.0
+    db = rng.uniform(-0.1, 0.1, N)
+    P = np.stack([rng.uniform(0.05, 1, N), rng.uniform(0.05, 1, N), 10 ** rng.uniform(-7, -3, N), 10 ** rng.uniform(-7, -3, N)], 1)
+    ph = rng.uniform(-np.pi, np.pi, (N, 4))
+    ph[::4] = 0.0                                     # the all-zero-phase shortcut of make_initial_amplitudes
+    res = pool.map(_g15_run, [(float(L[i]), int(n[i]), int(se[i]), float(gamma[i]), float(alpha[i]), float(db[i]), P[i], ph[i])
+                              for i in range(N)])
+    # n actually used upstream is int(round(L / dz)) with dz = L / n: record it from the saved grid
+    a_end = np.array([r[1][-1] for r in res])
+    p_max = np.array([np.max(np.abs(r[1][:, 2]) ** 2) for r in res])
+    n_rows = np.array([r[1].shape[0] for r in res])
+    z_last = np.array([r[0][-1] for r in res])
+    full = {f"A_full_{i}": res[i][1] for i in (0, 7, 19, 31)}
+    _save("G15", L=L, n=n, save_every=se, gamma=gamma, alpha=alpha, dbeta=db, p_in=P, phase_in=ph, A_end=a_end, p_max=p_max,
+          n_rows=n_rows, z_last=z_last, **full)
+
+
 def gen_g12():
     """Files written by the reference's io_fwm.save_run_bundle (tiny: 6 rows) -- pins the on-disk format."""
     import io_fwm
@@ -498,7 +537,7 @@ def main() -> None:
     with Pool(args.procs) as pool:
         for gid, fn, needs_pool in [("G1", gen_g1, False), ("G4", gen_g4, False), ("G5", gen_g5, False),
                                     ("G6", gen_g6, False), ("G7", gen_g7, False), ("G9", gen_g9, False),
-                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("API", gen_api_signatures, False), ("ERR", gen_error_contract, False), ("HOST", gen_host_api_records, False), ("G13", gen_g13, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
+                                    ("G10", gen_g10, False), ("G12", gen_g12, False), ("API", gen_api_signatures, False), ("ERR", gen_error_contract, False), ("HOST", gen_host_api_records, False), ("G13", gen_g13, True), ("G15", gen_g15, True), ("G2", gen_g2, True), ("G3", gen_g3, True),
                                     ("G11", gen_g11, True), ("G8", gen_g8, True)]:
             if want(gid):
                 print(f"{gid} ... ({time.perf_counter() - t0:.0f}s)", flush=True)

@@ -561,3 +561,32 @@ def test_a_trajectory_that_cannot_fit_is_refused_before_any_allocation():
     assert rc == -9 and b"does not fit" in L.psa_last_error()
     rc = L.psa_rk4_sweep_f64_dev(None, 4, 2**28, 10, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p)
     assert rc == -9                                                   # trajectory launches address lanes with 32 bits
+
+
+def test_g15_reference_robustness_draw_both_layouts(golden):
+    """G15 (generated from the reference): 32 single runs with every physical and numerical parameter random.  Each run is
+    its own launch (own step count and save stride), in both float64 lane layouts, against the reference's final row, max
+    signal power and -- for four runs, one with save_every = 1 -- the whole trajectory."""
+    g = golden("G15")
+    for i in range(32):
+        a0 = _a0(g["p_in"][i], g["phase_in"][i])
+        full = f"A_full_{i}" in g.files
+        for lanes in (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT):
+            got = nat.sweep_host([float(g["dbeta"][i])], n_steps=int(g["n"][i]), z_max=float(g["L"][i]),
+                                 save_every=int(g["save_every"][i]), gamma=float(g["gamma"][i]), alpha=float(g["alpha"][i]),
+                                 a0=a0, exact_step=True, want_traj=full, extra_flags=lanes)
+            assert got["first_bad_step"][0] == -1
+            assert rel_err(got["a_end"][0], g["A_end"][i]) < RTOL_F64, (i, lanes)
+            assert rel_err(got["p_max"][0], g["p_max"][i]) < RTOL_F64, (i, lanes)
+            if full:
+                assert got["traj"].shape[1] == int(g["n_rows"][i]) and rel_err(got["traj"][0], g[f"A_full_{i}"]) < RTOL_F64
+    # all 32 through the reference-shaped single-run API as well (its own n = int(round(L / dz)) rule)
+    from psa_amd import config, simulation
+    from psa_amd.phase_matching import PhaseMatchingConfig, PhaseMatchingMethod
+    for i in (0, 7, 19, 31):
+        cfg = config.custom_simulation_config(z_max=float(g["L"][i]), dz=float(g["L"][i]) / int(g["n"][i]), save_every=int(g["save_every"][i]))
+        pm = PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, provided_delta_beta=float(g["dbeta"][i]))
+        z, A = simulation.run_single_simulation(cfg, gamma=float(g["gamma"][i]), alpha=float(g["alpha"][i]), omega=np.full(4, 1.2e15),
+                                                p_in=g["p_in"][i], phase_in=g["phase_in"][i], phase_matching_cfg=pm)
+        assert A.shape == g[f"A_full_{i}"].shape and rel_err(A, g[f"A_full_{i}"]) < RTOL_F64
+        assert abs(z[-1] - g["z_last"][i]) <= 1e-12 * g["L"][i]

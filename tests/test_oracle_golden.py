@@ -200,3 +200,21 @@ def test_g13_legacy_betas_general_taylor_and_the_grid_rows(golden, oracle):
         r = oracle.sweep(db, z_max=250.0, n=1000, save_every=5, gamma=0.0115, alpha=1.0e-4, a0=a_grid)
         gain = oracle.gain_from_summary(r["p_max"], r["first_bad_step"], g["grid_p_in"][2], "db")
         np.testing.assert_allclose(gain, g["grid_gain_" + tag].ravel(), rtol=1e-11, atol=1e-11)
+
+
+def test_g15_robustness_draw_through_the_reference(golden, oracle):
+    """G15: 32 single runs of the REFERENCE with dbeta, gamma, alpha, all four powers and phases, fibre length, step count
+    and save stride drawn at random (SURVEY 8(d)'s robustness draw).  Final row, max signal power and four whole
+    trajectories (one of them with save_every = 1)."""
+    g = golden("G15")
+    worst = 0.0
+    for i in range(32):
+        a0 = _a0(g["p_in"][i], g["phase_in"][i])
+        z, A, bad = oracle.integrate(a0, z_max=float(g["L"][i]), n=int(g["n"][i]), save_every=int(g["save_every"][i]),
+                                     gamma=float(g["gamma"][i]), alpha=float(g["alpha"][i]), dbeta=float(g["dbeta"][i]))
+        assert bad == -1 and A.shape[0] == int(g["n_rows"][i])
+        assert abs(z[-1] - g["z_last"][i]) <= 1e-12 * g["L"][i]
+        worst = max(worst, rel_err(A[-1], g["A_end"][i]), rel_err(np.max(np.abs(A[:, 2]) ** 2), g["p_max"][i]))
+        if f"A_full_{i}" in g.files:
+            worst = max(worst, rel_err(A, g[f"A_full_{i}"]))
+    assert worst < 1e-11, worst

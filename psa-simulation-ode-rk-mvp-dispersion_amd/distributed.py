@@ -187,7 +187,7 @@ class DeviceSweep:
     """A rank's shard kept resident in HBM (torch tensors), launched on torch's current stream.
 
     Used by ``bench.py`` and by callers that chain sweeps without host round trips: float64 or float32, 4 or 6 waves
-    (``a0`` of length 6 + ``dbeta2_local``).  Layout is the SoA device layout of ``psa_rk4_sweep_f64_dev`` / ``_f32_dev``;
+    (``a0`` with 6 entries + ``dbeta2_local``); gamma / alpha a scalar or one value per point, a0 one vector or one per point.  Layout is the SoA device layout of ``psa_rk4_sweep_f64_dev`` / ``_f32_dev``;
     ``record`` is the int64-word image of ``RecordLayout`` that the kernel writes into directly and that
     ``gather()`` ships -- no packing pass.  ``pad_to`` (the widest block of the sharded sweep) makes records of ragged
     shards equally long.  dbeta comes either from the host (``dbeta_local``) or is generated on this GPU
@@ -195,16 +195,16 @@ class DeviceSweep:
     """
 
     def __init__(self, dbeta_local: Optional[np.ndarray] = None, *, n_steps: int, z_max: float, save_every: int,
-                 gamma: float, alpha: float, a0: np.ndarray, dbeta2_local: Optional[np.ndarray] = None,
+                 gamma, alpha, a0: np.ndarray, dbeta2_local: Optional[np.ndarray] = None,
                  n_local: Optional[int] = None, dtype=np.float64, check_nan: bool = True, exact_step: bool = False,
                  device: Optional[torch.device] = None, extra_flags: int = 0, pad_to: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceSweep needs a GPU: libpsa_hip has no CPU fallback")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         a0 = np.asarray(a0, dtype=np.complex128)
-        if a0.ndim != 1 or a0.shape[0] not in (4, 6):
-            raise ValueError("DeviceSweep: a0 must be one (4,) or (6,) complex vector (broadcast to every point)")
-        self.n_waves = int(a0.shape[0])
+        if a0.ndim not in (1, 2) or a0.shape[-1] not in (4, 6):
+            raise ValueError("DeviceSweep: a0 must be (n_waves,) (broadcast to every point) or (n_local, n_waves), n_waves 4 | 6")
+        self.n_waves = int(a0.shape[-1])
         self.layout = RecordLayout(self.n_waves, dtype)
         self.np_dtype = self.layout.dtype
         self.tdtype = _TORCH_DTYPE[self.np_dtype]
@@ -227,15 +227,34 @@ class DeviceSweep:
                 raise ValueError("dbeta2_local must match dbeta_local")
         elif dbeta2_local is not None:
             raise ValueError("dbeta2_local is only meaningful for six waves")
-        self.gamma = torch.tensor([float(gamma)], **opts)
-        self.alpha = torch.tensor([float(alpha)], **opts)
-        self.a0_soa = torch.tensor(np.stack([a0.real, a0.imag], 1).reshape(-1, 1), **opts).contiguous()   # [2*nw][1]
+        # gamma / alpha: a scalar (broadcast) or one value per point of the block; a0: one vector or one per point
+        bcast = 0
+
+        def per_point_or_scalar(x, name, flag):
+            nonlocal bcast
+            arr = np.atleast_1d(np.asarray(x, dtype=np.float64))
+            if arr.shape == (1,):
+                bcast |= flag
+            elif arr.shape != (self.n_local,):
+                raise ValueError(f"{name} must be a scalar or have one entry per point of the block ({self.n_local})")
+            return to_dev(arr)
+
+        self.gamma = per_point_or_scalar(gamma, "gamma", _native.BCAST_GAMMA)
+        self.alpha = per_point_or_scalar(alpha, "alpha", _native.BCAST_ALPHA)
+        if a0.ndim == 1:
+            bcast |= _native.BCAST_A0
+            a0 = a0[None, :]
+        elif a0.shape[0] != self.n_local:
+            raise ValueError(f"a0 must have one row per point of the block ({self.n_local})")
+        soa = np.empty((2 * self.n_waves, a0.shape[0]), dtype=np.float64)       # row 2j = Re A_j, 2j+1 = Im A_j
+        soa[0::2], soa[1::2] = a0.real.T, a0.imag.T
+        self.a0_soa = to_dev(soa).contiguous()
         self.pad_to = max(self.n_local, int(pad_to or 0))
         self.record = torch.zeros(self.layout.words(self.pad_to), dtype=torch.int64, device=self.device)
         self.traj = None    # optional [n_saved][n_waves][n_local][2] trajectory buffer (enable_trajectory)
-        self.flags = (_native.BCAST_GAMMA | _native.BCAST_ALPHA | _native.BCAST_A0 | int(extra_flags)
-                      | (_native.OPT_CHECK_NAN if check_nan else 0) | (_native.OPT_EXACT_STEP if exact_step else 0)
-                      | (_native.OPT_LOSSLESS if float(alpha) == 0.0 else 0))
+        lossless = bool(bcast & _native.BCAST_ALPHA) and float(np.asarray(alpha).reshape(-1)[0]) == 0.0
+        self.flags = (bcast | int(extra_flags) | (_native.OPT_CHECK_NAN if check_nan else 0)
+                      | (_native.OPT_EXACT_STEP if exact_step else 0) | (_native.OPT_LOSSLESS if lossless else 0))
         self._axes = {}
 
     # ---- record parts as device addresses -------------------------------------------------------------------

@@ -40,12 +40,10 @@ def test_device_gain_summary_and_gather_on_a_sweep_with_failing_points(oracle, r
     N = 1500
     rng = np.random.default_rng(8)
     db = rng.uniform(-0.05, 0.05, N)
-    ds = DeviceSweep(db, n_steps=1000, z_max=100.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A4, pad_to=N + 3)
-    # per-point gamma is not part of DeviceSweep's broadcast interface: swap in a per-point array and clear the flag
     gam = np.full(N, 0.0115)
     gam[::97] = 60.0
-    ds.gamma = torch.as_tensor(gam).to(ds.device)
-    ds.flags &= ~nat.BCAST_GAMMA
+    ds = DeviceSweep(db, n_steps=1000, z_max=100.0, save_every=10, gamma=gam, alpha=1.15e-4, a0=A4, pad_to=N + 3)
+    assert not ds.flags & nat.BCAST_GAMMA and ds.flags & nat.BCAST_ALPHA and ds.flags & nat.BCAST_A0
     ref = oracle.sweep(db, z_max=100.0, n=1000, save_every=10, gamma=gam, alpha=1.15e-4, a0=A4)
     for mode, key in (("max", "p_max"), ("end", "p_end")):
         ds.launch()
@@ -288,3 +286,27 @@ def test_six_wave_float32_shard_with_device_generated_pairs(oracle):
     assert np.max(np.abs(res.a_end.astype(complex) - ref["a_end"]) / scale) < RTOL_F32
     want = oracle.gain_from_summary(ref["p_max"], ref["first_bad_step"], P6[2], "db")
     assert np.max(np.abs(ds.gain.cpu().numpy().astype(float) - want)) < 2e-3
+
+
+def test_shard_object_with_per_point_gamma_alpha_and_amplitudes(oracle):
+    """DeviceSweep takes per-point gamma / alpha arrays and a (n_local, n_waves) amplitude matrix as well as the broadcast
+    forms; alpha == 0 as a scalar selects the lossless instantiation."""
+    import torch
+    from psa_amd.distributed import DeviceSweep
+    rng = np.random.default_rng(17)
+    n = 301
+    db = rng.uniform(-0.05, 0.05, n)
+    gam, al = rng.uniform(5e-3, 2e-2, n), rng.uniform(0, 3e-4, n)
+    a0 = np.sqrt(rng.uniform(1e-6, 0.8, (n, 4))) * np.exp(1j * rng.uniform(-3, 3, (n, 4)))
+    for kw in (dict(gamma=gam, alpha=al, a0=a0), dict(gamma=0.0115, alpha=al, a0=a0[5]), dict(gamma=gam, alpha=0.0, a0=a0)):
+        ds = DeviceSweep(db, n_steps=1500, z_max=150.0, save_every=10, **kw)
+        assert bool(ds.flags & nat.OPT_LOSSLESS) == (np.ndim(kw["alpha"]) == 0 and kw["alpha"] == 0.0)
+        ds.launch()
+        torch.cuda.synchronize()
+        ref = oracle.sweep(db, z_max=150.0, n=1500, save_every=10, **kw)
+        res = ds.result()
+        assert rel_err(res.a_end, ref["a_end"]) < RTOL_F64 and rel_err(res.p_max, ref["p_max"]) < RTOL_F64
+    with pytest.raises(ValueError):
+        DeviceSweep(db, n_steps=10, z_max=1.0, save_every=1, gamma=gam[:5], alpha=0.0, a0=a0)
+    with pytest.raises(ValueError):
+        DeviceSweep(db, n_steps=10, z_max=1.0, save_every=1, gamma=0.01, alpha=0.0, a0=a0[:7])

@@ -62,7 +62,7 @@ def _worker_variants(rank, world, port, n_points, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_points", [(2, 37), (2, 64), (3, 5)])
+@pytest.mark.parametrize("world,n_points", [(2, 37), (2, 64), (3, 5), (8, 45)])
 def test_float32_and_six_wave_records_through_gloo(tmp_path, oracle, world, n_points):
     mp.spawn(_worker_variants, args=(world, _free_port(), n_points, str(tmp_path)), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
@@ -106,7 +106,7 @@ def _worker(rank, world, port, n_points, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_points", [(2, 64), (2, 37), (2, 1), (4, 37), (4, 3)])
+@pytest.mark.parametrize("world,n_points", [(2, 64), (2, 37), (2, 1), (4, 37), (4, 3), (8, 67)])
 def test_multi_rank_gloo_sweep_equals_unsharded(tmp_path, oracle, world, n_points):
     mp.spawn(_worker, args=(world, _free_port(), n_points, str(tmp_path)), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")

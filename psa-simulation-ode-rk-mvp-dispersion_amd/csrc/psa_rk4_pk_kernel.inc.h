@@ -1,10 +1,11 @@
 // psa_rk4_pk_kernel.inc.h -- float32 sweep with TWO sweep points per lane (packed math), gfx950.
 //
-// Why: a float32 VALU instruction occupies a SIMD for 2 cycles per wave64, but a lone wave can only issue one every
-// 4 -- so the scalar float32 kernel runs no faster than the float64 one whenever a sweep gives each SIMD a single
-// wave (131 072 points per GPU in BASELINE config 4).  Packing points (2i, 2i+1) into the two halves of a 64-bit
-// register pair turns every instruction of the step into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
-// instruction count advances twice the points.  Same algorithm and arithmetic as the scalar float32 kernel
+// Why: on this chip a float32 VALU instruction without packing sustains the same one-per-4-cycles issue rate as float64
+// (tools/sp_peak.hip: v_fma_f32 tops out at 0.239 wave-instructions per clock per SIMD = 75 TFLOP/s at ANY occupancy), so a
+// one-point-per-lane float32 kernel runs no faster than the float64 one.  Packing points (2i, 2i+1) into the two halves of a
+// 64-bit register pair turns every instruction of the step into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
+// instruction count advances twice the points (129.5 TFLOP/s measured with one wave per SIMD -- the shape of BASELINE
+// config 4's per-GPU shard -- and 140-147 with four or more).  Same algorithm and arithmetic as the scalar float32 kernel
 // (classic low-storage RK4 on the un-fused RHS with a compensated state update, phase factor re-seeded from a
 // float64-reduced sincos every <= 24 steps), so the two agree to rounding.
 #pragma once

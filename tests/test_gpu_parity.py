@@ -590,3 +590,17 @@ def test_g15_reference_robustness_draw_both_layouts(golden):
                                                 p_in=g["p_in"][i], phase_in=g["phase_in"][i], phase_matching_cfg=pm)
         assert A.shape == g[f"A_full_{i}"].shape and rel_err(A, g[f"A_full_{i}"]) < RTOL_F64
         assert abs(z[-1] - g["z_last"][i]) <= 1e-12 * g["L"][i]
+
+
+def test_sixteen_million_points_in_one_launch(oracle):
+    """N = 2^24 + 12 345 (65 585 workgroups, a ragged last one; 1.5 GB of outputs): indices, the grid-stride gain reduction
+    and the ragged tail at a size where 32-bit products of (row, N) would overflow.  Sampled points against the oracle."""
+    N = (1 << 24) + 12_345
+    db = np.linspace(-0.05, 0.05, N)
+    got = nat.sweep_host(db, n_steps=40, z_max=4.0, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    pick = np.array([0, 1, 255, 256, 65_535, 65_536, N // 3, N // 2, (1 << 24) - 1, 1 << 24, N - 2, N - 1])
+    ref = oracle.sweep(db[pick], z_max=4.0, n=40, save_every=10, gamma=0.0115, alpha=1.15e-4, a0=A0)
+    assert rel_err(got["a_end"][pick], ref["a_end"]) < RTOL_F64 and rel_err(got["p_max"][pick], ref["p_max"]) < RTOL_F64
+    assert (got["first_bad_step"] == -1).all() and np.isfinite(got["p_max"]).all()
+    gain, bi, bg, nf = nat.gain_summary_host(got["p_max"], got["first_bad_step"], P_IN[2])
+    assert nf == N and bi == int(np.argmax(gain)) and bg == gain[bi]

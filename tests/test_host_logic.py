@@ -402,3 +402,38 @@ def test_scalar_host_api_is_bit_identical_to_the_reference_along_a_random_walk()
     wrong = [k for k in want if want[k] != got[k]]
     assert not wrong, (wrong[:5], want[wrong[0]], got[wrong[0]])
     assert sum(1 for v in want.values() if isinstance(v, list) and v and v[0] == "EXC") > 50
+
+
+def test_batch_producers_agree_with_the_scalar_api_point_by_point():
+    """Property test (hypothesis): for arbitrary wavelength triples -- in band, far out of band, zero, negative, NaN -- the
+    array producers that feed the sweep kernel (plan_from_wavelengths_batch, compute_phase_mismatch_batch) are valid exactly
+    where the scalar reference-shaped functions do not raise, and give the scalar dbeta there (bit-equal for the symmetric
+    closed form with squares only, within an ulp-scale relative error when x**4 goes through NumPy's array pow)."""
+    from hypothesis import given, settings, strategies as st
+    lam = st.one_of(st.floats(1.2e-6, 1.9e-6), st.floats(0.3e-6, 6e-6), st.sampled_from([0.0, -1.5e-6, float("nan"), float("inf")]))
+    d = dispersion.DispersionParams(omega_ref=frequency_plan.omega_from_lambda(1552e-9), beta2=-2.3e-28, beta3=4.1e-41, beta4=-3.0e-55)
+
+    @settings(max_examples=300, deadline=None)
+    @given(l1=lam, l2=lam, l3=lam, orders=st.sampled_from([(2, 4), (2,), (4, 2)]), general=st.booleans())
+    def check(l1, l2, l3, orders, general):
+        cfg = PhaseMatchingConfig(method="general_taylor", max_order=4) if general else PhaseMatchingConfig(even_orders=orders)
+        with np.errstate(all="ignore"):
+            om, ok = frequency_plan.plan_from_wavelengths_batch(np.array([l1]), np.array([l2]), np.array([l3]))
+            db, ok2 = phase_matching.compute_phase_mismatch_batch(om, d, cfg)
+        try:
+            om_s = frequency_plan.plan_from_wavelengths(l1, l2, l3)
+            db_s = phase_matching.compute_phase_mismatch(om_s, d, cfg).delta_beta
+            scalar_ok = bool(np.isfinite(db_s))
+        except (ValueError, TypeError):
+            scalar_ok = False
+        assert bool(ok[0] and ok2[0]) == scalar_ok, (l1, l2, l3)
+        if scalar_ok:
+            assert np.array_equal(om[0], om_s)
+            if not general and orders == (2,):
+                assert db[0] == db_s
+            else:
+                assert abs(db[0] - db_s) <= 1e-12 * abs(db_s) + 1e-30
+        else:
+            assert np.isnan(db[0])
+
+    check()

@@ -137,8 +137,9 @@ def _sweep_gain(*, cfg, lam1, lam2, lam3, gamma, alpha, p0, ph0, dispersion, pm_
                        beta_legacy=None, length_unit=length_unit)
         a0 = make_initial_amplitudes(p0, ph0)
         fiber, grid, pm = pre["fiber"], pre["grid"], pre["pm"].config
-        if grid_axes is not None:      # (lambda_p2 axis, lambda_signal axis) of a 2-D grid: lam2 / lam3 are its flattening
-            dbeta_m, ok = _grid_dbeta(lam1, grid_axes[0], grid_axes[1], fiber.dispersion, pm, dbeta_producer, device)
+        if grid_axes is not None:      # (lambda_p2 axis, lambda_signal axis) of a grid: lam2 / lam3 are its flattening
+            producer = _pick_producer(dbeta_producer, N, fiber.dispersion, pm)
+            dbeta_m, ok = _grid_dbeta(lam1, grid_axes[0], grid_axes[1], fiber.dispersion, pm, producer, device)
         else:
             omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
             dbeta_m, ok_db = compute_phase_mismatch_batch(omega, fiber.dispersion, pm)
@@ -197,9 +198,10 @@ def plot_max_signal_gain_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m:
         raise ValueError("yscale='log' is not supported with gain_unit='dB'. Use gain_unit='linear'.")
     _wavelength_axis(lam3, return_wavelength_unit)   # the reference raises this only AFTER its sweep; here before any device work
 
+    # a lambda3 sweep is the 1 x N case of the grid: sweeps of 4 096 points or more get their dbeta from the device producer
     gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
                              dispersion=dispersion, pm_cfg=phase_matching_cfg, length_unit=length_unit,
-                             gain_unit=unit)
+                             gain_unit=unit, grid_axes=(np.array([lam2]), lam3), dbeta_producer="auto")
     x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
 
     def draw(plt):
@@ -248,16 +250,17 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
         method=PhaseMatchingMethod.SYMMETRIC_EVEN, max_order=4, even_orders=(2, 4), atol=0.0, rtol=1e-12)
     _wavelength_axis(lam3, return_wavelength_unit)   # validated up front (upstream: after the sweep)
 
-    # dbeta in the caller's units: per point, NaN where the plan or the mismatch is invalid
+    # dbeta in the caller's units: per point, NaN where the plan or the mismatch is invalid (a lambda3 sweep is the 1 x N
+    # case of the grid: 4 096 points or more go through the device producer)
+    axes = (np.array([lam2]), lam3)
     try:
-        omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
-        dbeta, ok_db = compute_phase_mismatch_batch(omega, dispersion, pm_cfg)
-        dbeta = np.where(ok & ok_db, dbeta, np.nan)
+        dbeta, _ = _grid_dbeta(lam1, axes[0], axes[1], dispersion, pm_cfg, _pick_producer("auto", lam3.size, dispersion, pm_cfg), 0)
     except Exception:
         dbeta = np.full(lam3.shape, np.nan)
 
     gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
-                             dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit)
+                             dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
+                             grid_axes=axes, dbeta_producer="auto")
     gain = np.where(np.isnan(dbeta), np.nan, gain)   # a point whose dbeta failed never reaches the run upstream
     x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
     ref_line = -float(gamma) * float(p0[0] + p0[1])

@@ -166,7 +166,7 @@ def test_record_layout_properties_hold_for_arbitrary_splits():
     from hypothesis import given, settings, strategies as st
     from psa_amd.distributed import RecordLayout, shard_bounds, unpack_gathered
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=60, deadline=None, derandomize=True)
     @given(n=st.integers(0, 70), world=st.integers(1, 9), nw=st.sampled_from([4, 6]), f32=st.booleans(), seed=st.integers(0, 2**31))
     def check(n, world, nw, f32, seed):
         lay = RecordLayout(nw, np.float32 if f32 else np.float64)

@@ -413,7 +413,7 @@ def test_batch_producers_agree_with_the_scalar_api_point_by_point():
     lam = st.one_of(st.floats(1.2e-6, 1.9e-6), st.floats(0.3e-6, 6e-6), st.sampled_from([0.0, -1.5e-6, float("nan"), float("inf")]))
     d = dispersion.DispersionParams(omega_ref=frequency_plan.omega_from_lambda(1552e-9), beta2=-2.3e-28, beta3=4.1e-41, beta4=-3.0e-55)
 
-    @settings(max_examples=300, deadline=None)
+    @settings(max_examples=300, deadline=None, derandomize=True)
     @given(l1=lam, l2=lam, l3=lam, orders=st.sampled_from([(2, 4), (2,), (4, 2)]), general=st.booleans())
     def check(l1, l2, l3, orders, general):
         cfg = PhaseMatchingConfig(method="general_taylor", max_order=4) if general else PhaseMatchingConfig(even_orders=orders)
@@ -432,7 +432,13 @@ def test_batch_producers_agree_with_the_scalar_api_point_by_point():
             if not general and orders == (2,):
                 assert db[0] == db_s
             else:
-                assert abs(db[0] - db_s) <= 1e-12 * abs(db_s) + 1e-30
+                # NumPy's array pow and the scalar pow may differ by an ulp of x**4 (even pow(-x, 4) vs pow(x, 4)): allow a
+                # few ulp of the TERMS, which is all that is left when they cancel (e.g. lambda_signal == lambda_pump2)
+                w = om_s
+                oc = 0.5 * (w[0] + w[1])
+                big = max(abs(w[2] - oc), abs(0.5 * (w[0] - w[1])), abs(w[3] - d.omega_ref), abs(w[0] - d.omega_ref))
+                terms = abs(d.beta2) * big ** 2 + abs(d.beta3) * big ** 3 + abs(d.beta4) * big ** 4
+                assert abs(db[0] - db_s) <= 1e-12 * abs(db_s) + 4e-15 * terms
         else:
             assert np.isnan(db[0])
 

@@ -47,7 +47,11 @@ P_SIX = np.array([0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7])
 DBETA_RANGE = (-0.05, 0.05)
 
 # ---- accounting agreed in BASELINE.md section 2 / SURVEY 8(d); the 6-wave count follows the same rules --
-FLOPS_PER_RK4_STEP = {4: 652, 6: 1156}      # real flops per sweep point per z-step, + 2 (4) sincos not counted
+# 4 waves: SURVEY 8(d)'s count (652; the kernel executes 524 of them in 298 instructions).  6 waves: 2 flops x the 468 FP64
+# instructions of the one-lane step -- the most the vector ALU can execute for it.  The rule-by-rule count
+# of round 2 (1 156) credited a shared sum six times over and let a measured run reach 1.02 of the peak.
+FLOPS_PER_RK4_STEP = {4: 652, 6: 936}
+NOMINAL_GHZ = 2.4                            # the clock the 78.6 / 157.3 TFLOP/s peaks are quoted at
 PEAK_TFLOPS = {"f64": 78.6,                  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (vector FP64)
                "f32": 157.3}                 # the same with two packed float32 per lane (v_pk_fma_f32)
 PEAK_HBM_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -250,6 +254,30 @@ def trajectory_mode(args, dev, saved_stdout_fd) -> None:
     emit(out, saved_stdout_fd)
 
 
+def self_launch_command(n_gpus: int, argv, port: int | None = None) -> list:
+    """The command that starts one rank per GPU for `python bench.py --gpus N` (N > 1) run WITHOUT a launcher: the
+    contract's own `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` line
+    with this invocation's arguments passed through unchanged."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """Start the ranks as fresh child processes and wait for them.  Called before this process has made any GPU call
+    (`import torch` does not initialise HIP; torch.cuda.* would) and never replaces this process: rank 0's JSON line
+    reaches our stdout through the launcher, the exit status is the launcher's (non-zero if any rank failed)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(self_launch_command(n_gpus, list(argv)), env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,19 +302,23 @@ def main() -> None:
     cfg = CONFIGS[args.config]
     nw, n_z, pts = cfg["n_waves"], cfg["n_steps"], cfg["pts_per_gpu"]
 
-    # Exactly ONE line may reach stdout (the JSON, from rank 0).  RCCL prints a version banner with printf at
-    # communicator creation, so fd 1 is pointed at stderr for the run and restored only for the final print.
-    sys.stdout.flush()
-    saved_stdout_fd = os.dup(1)
-    os.dup2(2, 1)
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (nothing has touched the GPU yet)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        if args.mode == "trajectory":
+            raise SystemExit("--mode trajectory is a single-GPU measurement")
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # Exactly ONE line may reach stdout (the JSON, from rank 0).  RCCL prints a version banner with printf at
+    # communicator creation, so fd 1 is pointed at stderr for the run and restored only for the final print.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     # CPU legs first: one of them forks worker processes, which must happen before this process initialises the GPU
     # runtime -- so the GPU is detected from the device node, not through torch / HIP
     cpu_leg = None
@@ -322,14 +354,22 @@ def main() -> None:
     sweep, n_global, host_dbeta = build_shard(args.config, world, rank, dev, extra_flags=flags, exact_step=args.exact_step)
     p0_sig = float(cfg["p_in"][2])
 
-    def one_step(ev0=None, ev1=None):
-        if ev0 is not None:
-            ev0.record()                         # torch's current stream == the stream the kernel is launched on
+    def one_step(evs=None):
+        """launch -> gain reduction -> (all_gather) -> device-to-host copy of the outputs into pinned memory.  The copy is
+        enqueued on a second stream and the sweep switches to its other record, so pass k's copy overlaps pass k+1's kernel;
+        the synchronize that ends the timed region waits for the last copy: the clock is SURVEY 8(d)'s "kernel launch to
+        completed D2H of outputs (and completed gather)"."""
+        if evs is not None:
+            evs[0].record()                      # torch's current stream == the stream the kernel is launched on
         sweep.launch()
-        if ev1 is not None:
-            ev1.record()
+        if evs is not None:
+            evs[1].record()
         sweep.summarize(p0_sig, mode="max", gain_db=True)   # the drivers' per-point gain + argmax, on device
-        return sweep.gather() if use_dist else None
+        g = sweep.gather() if use_dist else None
+        if evs is not None:
+            evs[2].record()
+        sweep.stage_to_host(g)
+        return g
 
     for _ in range(args.warmup):
         one_step()
@@ -337,12 +377,12 @@ def main() -> None:
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     gathered = None
-    for e0, e1 in events:
-        gathered = one_step(e0, e1)
-    torch.cuda.synchronize()
+    for evs in events:
+        gathered = one_step(evs)
+    torch.cuda.synchronize()                     # every stream of the device: kernels, gathers and host copies
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -351,12 +391,19 @@ def main() -> None:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    resident_ms = float(np.mean([e[0].elapsed_time(e[2]) for e in events]))   # launch .. gain (.. gather), outputs left in HBM
+    host_words, host_summ = sweep.host_result()
 
     # -- post-run guard (not timed): the numbers just produced are the right numbers
-    res = sweep.result()
+    # ... read from the PINNED HOST image the timed passes delivered (this rank's row of the gathered records for N > 1)
+    host_words = host_words.reshape(world if use_dist else 1, -1)
+    a_h, pe_h, pm_h, fb_h = sweep.layout.unpack(host_words[rank if use_dist else 0], pts)
+    from psa_amd.sweep import SweepResult
+    res = SweepResult(a_h, pe_h, pm_h, fb_h, n_z, SAVE_EVERY, kern_ms)
     if use_dist:
         assert gathered is not None and torch.equal(gathered[rank], sweep.record)
+        assert np.array_equal(host_words[rank], sweep.record.cpu().numpy())
     verify = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -370,13 +417,13 @@ def main() -> None:
                       a0=np.sqrt(cfg["p_in"]).astype(complex), threads=4,
                       **({"dbeta2": sweep.dbeta2.cpu().numpy()[pick].astype(np.float64)} if nw == 6 else {}))
         err = float(np.max(np.abs(res.a_end[pick].astype(complex) - ref["a_end"]) / np.abs(ref["a_end"])))
-        gain_dev = sweep.gain.cpu().numpy().astype(np.float64)
+        gain_dev = host_summ[0].astype(np.float64)
         gain_ref = O.gain_from_summary(ref["p_max"], ref["first_bad_step"], p0_sig, "db")
-        best_i, n_fin = (int(v) for v in sweep.best.cpu().numpy())
+        best_i, n_fin = (int(v) for v in host_summ[1])
         err_gain = float(np.max(np.abs(gain_dev[pick] - gain_ref)))
         verify = {"points_checked_vs_oracle": int(pick.size), "max_rel_err_a_end": err, "max_err_gain_db": err_gain,
                   "max_rel_err_dbeta_device_vs_host": err_db,
-                  "all_finite": bool((res.first_bad_step == -1).all()), "best_gain_db": float(sweep.best_gain.item()),
+                  "all_finite": bool((res.first_bad_step == -1).all()), "best_gain_db": float(host_summ[2][0]),
                   "best_index": best_i}
         tol_a, tol_g, tol_db = (1e-4, 5e-4, 1e-7) if f32 else (1e-9, 5e-9, 4e-16)
         if not (err < tol_a and err_gain < tol_g and err_db <= tol_db and verify["all_finite"] and n_fin == pts
@@ -396,6 +443,20 @@ def main() -> None:
         ipw = facts.get("valu_insts_per_wave_step")
         # lanes that carry one sweep point: 1 (one lane per point), 0.5 (float32 packed: two points per lane), 2 (split)
         lanes_per_point = facts.get("lanes_per_point", 1.0)
+        # -- the same launch in HARDWARE units (what the vector ALU was asked to do, not what the algorithm is credited with):
+        #    every VALU wave-instruction holds its SIMD for 4 cycles (wave64 on 16 lanes), FP64 and packed FP32 alike.
+        kern_s = kern_ms * 1e-3
+        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        waves = -(-int(round(pts * lanes_per_point)) // 64)
+        issue_nominal = None if ipw is None else ipw * waves * n_z * 4 / (simds * NOMINAL_GHZ * 1e9 * kern_s)
+        ex_lane = facts.get("executed_flops_per_lane_step")      # (2 FMA + MUL + ADD [x2 packed]) per lane per z-step, PMC
+        executed = None
+        if ex_lane is not None:
+            ex_tflops = ex_lane * 64 * waves * n_z / kern_s / 1e12
+            executed = {"flops_per_lane_step": ex_lane, "achieved": ex_tflops, "unit": "TFLOP/s", "frac": ex_tflops / peak,
+                        "counters": facts.get("executed_flops_counters"),
+                        "note": "flops the VALU executed per the SQ_INSTS_VALU_{FMA,MUL,ADD} pass of profiles/ (an FMA = 2), "
+                                "scaled to this run's kernel time: the fraction of the dense vector peak actually used"}
         out = {
             "metric": "RK4 field-point updates/sec (sweep_pts x n_fields x n_zsteps / wall_s)",
             "value": value, "unit": "field-point updates/s", "n_gpus": world, "steps": args.steps,
@@ -408,6 +469,13 @@ def main() -> None:
                                        f"REHEARSAL: {world} ranks over {n_dev} GPU(s), {backend} gather staged through the host")
                        if world > 1 else "single GPU"},
             "rk4_steps_per_s": value / nw,
+            # the clock of `value`: launch -> gain reduction -> (gather) -> outputs complete in pinned host memory,
+            # the copy of pass k overlapped with the kernel of pass k+1 on a second stream.  The figure with the outputs
+            # left in HBM (launch .. gather, HIP events on the launch stream) is kept beside it:
+            "value_clock": "kernel launch to completed D2H of the outputs (and completed gather), K passes back to back",
+            "value_device_resident": updates_per_step / (resident_ms * 1e-3),   # rank 0's events
+            "device_resident_ms_per_step": resident_ms,
+            "d2h_bytes_per_step": int(host_words.nbytes + sum(t.nbytes for t in host_summ)),
             "roofline": {
                 "kernel": facts.get("kernel"),
                 "bound": "mfma",   # the contract's label for the COMPUTE roofline (enum hbm | mfma); see bound_detail
@@ -415,7 +483,14 @@ def main() -> None:
                                 "recurrence, nothing to contract); for float64 the MI355X vector and matrix dense peaks are "
                                 "the same 78.6 TFLOP/s, for float32 the peak used is the packed-vector rate 157.3 TFLOP/s",
                 "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                "frac_is": "ALGORITHMIC flops (flops_per_rk4_step x points x z-steps, SURVEY 8d accounting) / kernel time / "
+                           "peak -- the contract's definition; it credits 652 flops where the kernel executes 524 in 298 "
+                           "instructions, so it can exceed the issue-slot utilisation: read issue_frac_nominal and executed",
+                "issue_frac_nominal": issue_nominal, "issue_frac_nominal_is": "VALU wave-instructions x 4 cycles / (SIMDs x "
+                                                                              f"{NOMINAL_GHZ} GHz x kernel time)",
+                "executed": executed,
                 "flops_per_launch": flops, "flops_per_rk4_step": FLOPS_PER_RK4_STEP[nw], "kernel_ms_avg": kern_ms,
+                "waves_per_launch": waves, "simds": simds,
                 # VALU wave-instructions per z-step (SQ_INSTS_VALU, profiles/kernels.json) x 4 issue cycles: the clock the chip
                 # would need if the vector pipe never idled = a LOWER bound on the clock it held.  Boxes of the pool differ
                 # by ~10 % here (DVFS / silicon), which moves `frac` with no change in the code.

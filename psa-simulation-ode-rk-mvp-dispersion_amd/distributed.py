@@ -117,10 +117,11 @@ def _native_executor(dbeta, **kw):
     return _native.sweep_host(dbeta, **kw)
 
 
-def _all_gather_words(t_local: torch.Tensor, world: int, group) -> torch.Tensor:
+def _all_gather_words(t_local: torch.Tensor, world: int, group, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The single collective of the path: every rank contributes the same number of int64 words."""
-    out = torch.empty(world * t_local.numel(), dtype=torch.int64, device=t_local.device)
-    dist.all_gather_into_tensor(out, t_local, group=group)
+    if out is None:
+        out = torch.empty(world * t_local.numel(), dtype=torch.int64, device=t_local.device)
+    dist.all_gather_into_tensor(out.view(-1), t_local, group=group)
     return out.view(world, t_local.numel())
 
 
@@ -250,16 +251,33 @@ class DeviceSweep:
         soa[0::2], soa[1::2] = a0.real.T, a0.imag.T
         self.a0_soa = to_dev(soa).contiguous()
         self.pad_to = max(self.n_local, int(pad_to or 0))
-        self.record = torch.zeros(self.layout.words(self.pad_to), dtype=torch.int64, device=self.device)
+        # Two records, used alternately once `stage_to_host` is in play: launch k+1 writes one while the copy engine
+        # still reads launch k's from the other (`record` is always the one the next / latest launch writes).
+        self._records = [torch.zeros(self.layout.words(self.pad_to), dtype=torch.int64, device=self.device)]
+        self._cur = 0                      # the record the NEXT launch writes
+        self._last = 0                     # the record the latest launch wrote
+        self._copy_stream = None
+        self._host = [None, None]          # pinned images of (record | gathered records) per buffer
+        self._host_gain = [None, None]
+        self._copied = [None, None]        # event: the copy out of buffer b has finished
+        self._gathered = [None, None]
+        self._summ = [None, None]          # (gain, [best_index, n_finite], best_gain) of the latest summarize per buffer
+        self._ws = None
         self.traj = None    # optional [n_saved][n_waves][n_local][2] trajectory buffer (enable_trajectory)
         lossless = bool(bcast & _native.BCAST_ALPHA) and float(np.asarray(alpha).reshape(-1)[0]) == 0.0
         self.flags = (bcast | int(extra_flags) | (_native.OPT_CHECK_NAN if check_nan else 0)
                       | (_native.OPT_EXACT_STEP if exact_step else 0) | (_native.OPT_LOSSLESS if lossless else 0))
         self._axes = {}
 
+    @property
+    def record(self) -> torch.Tensor:
+        """The record of the latest launch (int64 words, RecordLayout)."""
+        return self._records[self._last]
+
     # ---- record parts as device addresses -------------------------------------------------------------------
-    def _part(self, name: str) -> int:
-        return self.record.data_ptr() + self.layout.offsets(self.n_local)[name]
+    def _part(self, name: str, which: Optional[int] = None) -> int:
+        rec = self._records[self._cur if which is None else which]
+        return rec.data_ptr() + self.layout.offsets(self.n_local)[name]
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -292,6 +310,7 @@ class DeviceSweep:
     # ---- the sweep ------------------------------------------------------------------------------------------------
     def launch(self) -> None:
         """Asynchronous: enqueue the sweep kernel on torch's current stream."""
+        self._last = self._cur
         _native.sweep_device(stream=self._stream(), n_waves=self.n_waves, n_points=self.n_local,
                              n_steps=self.n_steps, z_max=self.z_max, save_every=self.save_every,
                              d_dbeta=self.dbeta.data_ptr(), d_dbeta2=(self.dbeta2.data_ptr() if self.dbeta2 is not None else 0),
@@ -305,14 +324,17 @@ class DeviceSweep:
         fills ``self.gain`` (n_local,), ``self.best`` = [best_index, n_finite] (int64) and ``self.best_gain`` (1,)."""
         if mode not in ("end", "max"):
             raise ValueError(f"Unknown gain_mode={mode!r}. Use 'end' or 'max'.")
-        if not hasattr(self, "gain"):
-            self.gain = torch.empty(self.n_local, dtype=self.tdtype, device=self.device)
-            self.best = torch.zeros(2, dtype=torch.int64, device=self.device)
-            self.best_gain = torch.zeros(1, dtype=torch.float64, device=self.device)
+        b = self._last
+        if self._summ[b] is None:
+            self._summ[b] = (torch.empty(self.n_local, dtype=self.tdtype, device=self.device),
+                             torch.zeros(2, dtype=torch.int64, device=self.device),
+                             torch.zeros(1, dtype=torch.float64, device=self.device))
+        if self._ws is None:
             self._ws = torch.empty(_native.gain_summary_workspace_bytes(self.n_local), dtype=torch.uint8, device=self.device)
+        self.gain, self.best, self.best_gain = self._summ[b]
         _native.gain_summary_device(stream=self._stream(), n_points=self.n_local,
-                                    d_p_metric=self._part("p_max" if mode == "max" else "p_end"),
-                                    d_first_bad=self._part("first_bad"), p0_sig=p0_sig, gain_db=gain_db,
+                                    d_p_metric=self._part("p_max" if mode == "max" else "p_end", b),
+                                    d_first_bad=self._part("first_bad", b), p0_sig=p0_sig, gain_db=gain_db,
                                     d_gain=self.gain.data_ptr(), d_best_index=self.best.data_ptr(),
                                     d_best_gain=self.best_gain.data_ptr(), d_n_finite=self.best.data_ptr() + 8,
                                     d_workspace=self._ws.data_ptr(), dtype=self.np_dtype)
@@ -324,15 +346,62 @@ class DeviceSweep:
         return self.traj.numel() * self.traj.element_size()
 
     def gather(self, group=None) -> torch.Tensor:
-        """One all_gather of the record over the process group -> (world, words(pad_to)) int64 on this GPU.  Every rank
-        must have been built with the same ``pad_to`` (the widest block); trim with ``unpack_gathered``."""
+        """One all_gather of the latest record over the process group -> (world, words(pad_to)) int64 on this GPU.  Every
+        rank must have been built with the same ``pad_to`` (the widest block); trim with ``unpack_gathered``.  The result
+        lives in a buffer owned by this object (one per record), reused by the launch after next."""
         world = dist.get_world_size(group)
+        b = self._last
+        if self._gathered[b] is None or self._gathered[b].shape[0] != world:
+            self._gathered[b] = torch.empty((world, self.record.numel()), dtype=torch.int64, device=self.device)
         if dist.get_backend(group) != "nccl":
             # rehearsal backend (gloo: several ranks sharing one GPU, or CPU-only hosts): the same words, staged through
             # the host because gloo has no device-side all_gather_into_tensor
-            return _all_gather_words(self.record.cpu(), world, group).to(self.device)
+            self._gathered[b].copy_(_all_gather_words(self.record.cpu(), world, group))
+            return self._gathered[b]
         with torch.cuda.device(self.device):
-            return _all_gather_words(self.record, world, group)
+            return _all_gather_words(self.record, world, group, out=self._gathered[b])
+
+    def stage_to_host(self, gathered: Optional[torch.Tensor] = None) -> None:
+        """Enqueue the device-to-host copy of the latest pass's outputs -- the record (or ``gathered``, every rank's) and,
+        if ``summarize`` ran, the gains and the argmax -- into pinned host memory on a SECOND stream, then switch to the
+        other record so that the next launch can start at once: the copy of pass k rides under the kernel of pass k + 1.
+        Stream order is kept by events both ways (copy after the producers of pass k; the launch that reuses a buffer
+        after the copy that read it).  ``host_result()`` returns the image after a synchronize."""
+        b = self._last
+        cur = torch.cuda.current_stream(self.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        if len(self._records) == 1:
+            self._records.append(torch.zeros_like(self._records[0]))
+        src = (self._records[b] if gathered is None else gathered).view(-1)
+        if self._host[b] is None or self._host[b].numel() != src.numel():
+            self._host[b] = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
+        summ = self._summ[b]
+        if summ is not None and self._host_gain[b] is None:
+            self._host_gain[b] = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in summ)
+        produced = torch.cuda.Event()
+        produced.record(cur)
+        self._copy_stream.wait_event(produced)
+        with torch.cuda.stream(self._copy_stream):
+            self._host[b].copy_(src, non_blocking=True)
+            if summ is not None:
+                for h, t in zip(self._host_gain[b], summ):
+                    h.copy_(t, non_blocking=True)
+            self._copied[b] = torch.cuda.Event()
+            self._copied[b].record(self._copy_stream)
+        self._cur = b ^ 1
+        if self._copied[self._cur] is not None:      # the pass before last read this buffer: long done, but say so
+            cur.wait_event(self._copied[self._cur])
+
+    def host_result(self):
+        """(words, (gain, best, best_gain) | None) of the latest staged pass as NumPy views of the pinned buffers.
+        The caller synchronizes first (``torch.cuda.synchronize`` or the event in ``_copied``)."""
+        b = self._last
+        if self._copied[b] is None:
+            raise RuntimeError("nothing staged: call stage_to_host() after launch()")
+        self._copied[b].synchronize()
+        g = self._host_gain[b]
+        return self._host[b].numpy(), (None if g is None else tuple(t.numpy() for t in g))
 
     def result(self) -> SweepResult:
         a, pe, pm, fb = self.layout.unpack(self.record.cpu().numpy(), self.n_local)

@@ -32,7 +32,8 @@ import torch.distributed as dist
 from . import _native
 from .sweep import SweepResult
 
-__all__ = ["shard_bounds", "RecordLayout", "unpack_gathered", "sweep_sharded", "DeviceSweep"]
+__all__ = ["shard_bounds", "RecordLayout", "unpack_gathered", "all_gather_host_words", "local_device", "sweep_sharded",
+           "DeviceSweep"]
 
 
 def shard_bounds(n_points: int, world: int, rank: int) -> Tuple[int, int]:
@@ -125,6 +126,27 @@ def _all_gather_words(t_local: torch.Tensor, world: int, group, out: Optional[to
     return out.view(world, t_local.numel())
 
 
+def all_gather_host_words(words: np.ndarray, group=None, device: Optional[int] = None) -> np.ndarray:
+    """Host int64 words in, (world, n_words) host words out: the one collective of a sharded sweep for callers whose
+    blocks live in host buffers (``sweep_sharded``, the ``scan_mismtach`` drivers).  Under ``nccl`` (RCCL) the words
+    ride through the GPU that computed the block (``device``; default: the current one); under ``gloo`` they stay on
+    the host.  Every rank must contribute the same number of words."""
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(words, dtype=np.int64))
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", int(device) if device is not None else torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            return _all_gather_words(t.to(dev), world, group).cpu().numpy()
+    return _all_gather_words(t, world, group).numpy()
+
+
+def local_device(group=None) -> int:
+    """The GPU a rank of a one-process-per-GPU job drives: LOCAL_RANK (torchrun), else rank modulo the visible GPUs."""
+    import os
+    n = max(1, _native.device_count())
+    return int(os.environ.get("LOCAL_RANK", dist.get_rank(group))) % n
+
+
 def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, gamma, alpha, a0, dbeta2=None,
                   check_nan: bool = True, dtype=np.float64, group=None, device: Optional[int] = None,
                   executor: Optional[Callable[..., dict]] = None) -> SweepResult:
@@ -168,14 +190,8 @@ def sweep_sharded(dbeta, *, n_steps: int, z_max: float, save_every: int = 10, ga
 
     width = (N + world - 1) // world                     # widest shard; shorter ones are zero-padded
     words = layout.pack(local["a_end"], local["p_end"], local["p_max"], local["first_bad_step"], pad_to=width)
-    if dist.get_backend(group) == "nccl":
-        # the collective runs on the GPU that computed the shard, also for a rank whose block is empty
-        dev_index = kw.get("device", int(device) if device is not None else torch.cuda.current_device())
-        dev = torch.device("cuda", int(dev_index))
-        with torch.cuda.device(dev):
-            gathered = _all_gather_words(torch.from_numpy(words).to(dev), world, group).cpu().numpy()
-    else:
-        gathered = _all_gather_words(torch.from_numpy(words), world, group).numpy()
+    # the collective runs on the GPU that computed the shard, also for a rank whose block is empty
+    gathered = all_gather_host_words(words, group, device=kw.get("device", device))
     a_end, p_end, p_max, first_bad = unpack_gathered(layout, gathered, N, world)
     return SweepResult(a_end, p_end, p_max, first_bad, int(n_steps), int(save_every),
                        float(local.get("elapsed_ms", 0.0)))

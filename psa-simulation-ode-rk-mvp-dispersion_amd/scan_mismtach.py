@@ -13,6 +13,12 @@ Where the reference loops over lambda3 in Python and calls ``run_single_simulati
 build every plan and every dbeta at once on the host (``plan_from_wavelengths_batch``,
 ``compute_phase_mismatch_batch``), launch ONE HIP sweep over all valid points and reduce the gain on the GPU.
 
+Several GPUs (the reference's loop over points is embarrassingly parallel, scan_mismtach.py:357-392, :694-738):
+* under a ``torch.distributed`` process group (one process per GPU, ``torchrun``) every driver splits its points into
+  contiguous blocks, each rank produces the phase mismatch of ITS block (on its GPU with the device producer), integrates it
+  and contributes the block's output record to ONE all_gather (RCCL under ``nccl``); every rank returns the full arrays;
+* a plain Python caller passes ``devices=[0, 1, ...]``: one host thread per GPU over ``psa_rk4_sweep_f64(device=k)``.
+
 Failure conventions kept from the reference: malformed arguments raise ``ValueError`` up front
 (:315-349, :630-671); anything that would raise INSIDE the per-point ``try`` (an impossible plan, a bad cfg,
 FloatingPointError from ``check_nan``) never raises -- the point's gain (and dbeta) is NaN (:391-392, :736-738).
@@ -87,18 +93,110 @@ def _wavelength_axis(lam3, unit):
     raise ValueError("return_wavelength_unit must be 'm' or 'nm'")
 
 
+# ---- how a driver call's points are divided --------------------------------------------------------------------
+class _Shard:
+    """This process's share [lo, hi) of a driver call over n points: everything when no process group is up."""
+
+    def __init__(self, n: int, device: Optional[int]):
+        import sys
+        self.n, self.world, self.rank, self.group = int(n), 1, 0, None
+        td = sys.modules.get("torch.distributed")      # a caller who initialised a process group has imported it
+        if td is not None and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+            self.world, self.rank = td.get_world_size(), td.get_rank()
+        if self.world > 1:
+            from .distributed import local_device, shard_bounds
+            self.lo, self.hi = shard_bounds(self.n, self.world, self.rank)
+            self.device = local_device() if device is None else int(device)
+        else:
+            self.lo, self.hi = 0, self.n
+            self.device = 0 if device is None else int(device)
+        self.width = -(-self.n // self.world)            # widest block
+
+    @property
+    def sharded(self) -> bool:
+        return self.world > 1
+
+    def block(self, x, per_point_ndim: int = 1):
+        """This rank's rows of a per-point argument; scalars and single rows pass through."""
+        x = np.asarray(x)
+        return x[self.lo:self.hi] if (x.ndim == per_point_ndim and x.shape[0] == self.n and self.n > 1) else x
+
+
+NEVER_RAN = -2    # first_bad_step of a point whose plan / dbeta was invalid: it never reached the kernel
+
+
+def _run_block(shard: _Shard, ok_blk, dbeta_blk, *, dbeta2_blk=None, extras=(), n_waves=4, dtype=np.float64, devices=None,
+               **run_kw):
+    """Integrate the valid points of this process's block and, when the call is sharded over a process group, exchange
+    the blocks: ONE all_gather of [output record | extras], every rank ends up with the whole sweep.
+
+    ok_blk, dbeta_blk (, dbeta2_blk): the block's validity mask and per-metre mismatch; ``extras``: per-point float64
+    arrays of the block that travel with the record (the caller-unit dbeta).  run_kw: rk4_sweep's arguments, per-point
+    ones already cut to the block.  Returns (SweepResult over the valid points of the WHOLE sweep in order | None,
+    ok[n], [extras over n])."""
+    ok_blk = np.asarray(ok_blk, dtype=bool)
+    idx = np.flatnonzero(ok_blk)
+    res = None
+    if idx.size:
+        kw = dict(run_kw)
+        for name, nd in (("gamma", 1), ("alpha", 1), ("a0", 2)):
+            v = np.asarray(kw[name])
+            if v.ndim == nd and v.shape[0] == ok_blk.size and ok_blk.size > 1:
+                kw[name] = v[idx]
+        res = rk4_sweep(np.asarray(dbeta_blk)[idx], dbeta2=(None if dbeta2_blk is None else np.asarray(dbeta2_blk)[idx]),
+                        dtype=dtype, device=shard.device, devices=(None if shard.sharded else devices), **kw)
+    if not shard.sharded:
+        return res, ok_blk, [np.asarray(e) for e in extras]
+
+    from .distributed import RecordLayout, all_gather_host_words, shard_bounds
+    layout = RecordLayout(n_waves, dtype)
+    nb = ok_blk.size
+    a_end = np.full((nb, n_waves), np.nan, dtype=layout.cdtype)
+    p_end, p_max = np.full(nb, np.nan, dtype=layout.dtype), np.full(nb, np.nan, dtype=layout.dtype)
+    bad = np.full(nb, NEVER_RAN, dtype=np.int64)
+    if res is not None:
+        a_end[idx], p_end[idx], p_max[idx], bad[idx] = res.a_end, res.p_end, res.p_max, res.first_bad_step
+    parts = [layout.pack(a_end, p_end, p_max, bad, pad_to=shard.width)]
+    for e in extras:
+        buf = np.zeros(shard.width, dtype=np.float64)
+        buf[:nb] = e
+        parts.append(buf.view(np.int64))
+    gathered = all_gather_host_words(np.concatenate(parts), shard.group, device=shard.device)
+    nrec = layout.words(shard.width)
+    cols, ext = [[], [], [], []], [[] for _ in extras]
+    for r in range(shard.world):
+        lo, hi = shard_bounds(shard.n, shard.world, r)
+        for c, part in zip(cols, layout.unpack(gathered[r, :nrec], hi - lo)):
+            c.append(part)
+        for k in range(len(extras)):
+            ext[k].append(gathered[r, nrec + k * shard.width: nrec + k * shard.width + (hi - lo)].view(np.float64))
+    a_end, p_end, p_max, bad = (np.concatenate(c) for c in cols)
+    ok = bad != NEVER_RAN
+    full = None
+    if ok.any():
+        full = SweepResult(a_end[ok], p_end[ok], p_max[ok], bad[ok], int(run_kw["n_steps"]), int(run_kw["save_every"]),
+                           0.0 if res is None else res.elapsed_ms)
+    return full, ok, [np.concatenate(e) for e in ext]
+
+
 # ---- the engine call shared by the drivers ------------------------------------------------------------------
-def _grid_dbeta(lam1, lam2_axis, lam3_axis, disp, pm_cfg, producer, device):
-    """dbeta and validity of every point of the flattened lambda_p2 x lambda_signal grid (row-major).
+def _grid_dbeta(lam1, lam2_axis, lam3_axis, disp, pm_cfg, producer, device, lo=0, hi=None):
+    """dbeta and validity of points [lo, hi) of the flattened lambda_p2 x lambda_signal grid (row-major; default: all).
     producer "host": the NumPy array restatement (frequency_plan / phase_matching ``*_batch``);
-    producer "device": the same operations on the GPU (psa_dbeta_grid_f64, csrc/psa_dbeta.hip) -- what multi-GPU shards use."""
+    producer "device": the same operations on the GPU (psa_dbeta_grid_f64, csrc/psa_dbeta.hip) -- a rank of a sharded sweep
+    produces exactly its own block, so no per-point input ever travels."""
+    ax2, ax3 = np.atleast_1d(lam2_axis), np.atleast_1d(lam3_axis)
+    hi = ax2.size * ax3.size if hi is None else hi
     if producer == "device":
         from . import _native
-        return _native.dbeta_grid_host(_native.dbeta_model(disp, pm_cfg), float(lam1), lam2_axis, lam3_axis, device=device)
+        if hi == lo:
+            return np.zeros(0), np.zeros(0, dtype=bool)
+        return _native.dbeta_grid_host(_native.dbeta_model(disp, pm_cfg), float(lam1), ax2, ax3, first=lo, n_points=hi - lo,
+                                       device=device)
     if producer != "host":
         raise ValueError("dbeta_producer must be 'host' or 'device'")
-    L2, L3 = np.meshgrid(np.atleast_1d(lam2_axis), np.atleast_1d(lam3_axis), indexing="ij")
-    omega, ok = plan_from_wavelengths_batch(float(lam1), L2.ravel(), L3.ravel())
+    i = np.arange(lo, hi)
+    omega, ok = plan_from_wavelengths_batch(float(lam1), ax2[i // ax3.size], ax3[i % ax3.size])
     db, ok_db = compute_phase_mismatch_batch(omega, disp, pm_cfg)
     ok = ok & ok_db
     return np.where(ok, db, np.nan), ok
@@ -107,7 +205,8 @@ def _grid_dbeta(lam1, lam2_axis, lam3_axis, disp, pm_cfg, producer, device):
 def _pick_producer(choice, n_points, disp, pm_cfg, even_orders=None):
     """"host" | "device" | "auto": auto takes the device producer for grids of 4 096 points or more when the model is one
     it covers (the NumPy producer costs ~0.2 us per point, 230 ms on BASELINE config 3's 1024 x 1024 grid against 19 ms
-    of host time with the device producer; the two agree bit for bit on the reference's vectors)."""
+    of host time with the device producer; the two agree bit for bit on the reference's vectors).  The
+    choice follows the size of the WHOLE sweep, so a sharded call picks what the unsharded one would."""
     if choice in ("host", "device"):
         return choice
     if choice != "auto":
@@ -122,40 +221,57 @@ def _pick_producer(choice, n_points, disp, pm_cfg, even_orders=None):
         return "host"
 
 
-def _sweep_gain(*, cfg, lam1, lam2, lam3, gamma, alpha, p0, ph0, dispersion, pm_cfg, length_unit, gain_unit,
-                gain_mode="max", device=0, grid_axes=None, dbeta_producer="host"):
-    """Everything the reference does inside its per-point ``try``, for all points at once.
+def _sweep_gain(*, cfg, lam1, grid_axes, gamma, alpha, p0, ph0, dispersion, pm_cfg, length_unit, gain_unit,
+                gain_mode="max", device=None, devices=None, dbeta_producer="host", caller_dbeta=None):
+    """Everything the reference does inside its per-point ``try``, for all points of the lambda_p2 x lambda_signal grid
+    ``grid_axes`` at once (a lambda3 sweep is its 1 x N case).
 
-    Returns (gain[N], dbeta_m[N] per metre, SweepResult | None).  Never raises for per-point or cfg problems:
-    those become NaN, as ``except Exception`` does upstream.
+    ``caller_dbeta = (dispersion as given, pm_cfg)`` also produces the drivers' returned dbeta (1/length_unit, computed
+    from the UNSCALED dispersion like scan_mismtach.py:700-706) block by block.  Returns (gain[N], dbeta_caller[N] | None,
+    SweepResult | None).  Never raises for per-point or cfg problems: those become NaN, as ``except Exception`` does upstream.
     """
-    N = lam3.size
+    ax2, ax3 = np.atleast_1d(grid_axes[0]), np.atleast_1d(grid_axes[1])
+    N = ax2.size * ax3.size
+    shard = _Shard(N, device)
     gain = np.full(N, np.nan)
+    nb = shard.hi - shard.lo
     try:
         # plan-independent part of run_single_simulation (validation, unit scaling, containers)
         pre = _prepare(cfg, gamma=gamma, alpha=alpha, dispersion=dispersion, phase_matching_cfg=pm_cfg,
                        beta_legacy=None, length_unit=length_unit)
         a0 = make_initial_amplitudes(p0, ph0)
         fiber, grid, pm = pre["fiber"], pre["grid"], pre["pm"].config
-        if grid_axes is not None:      # (lambda_p2 axis, lambda_signal axis) of a grid: lam2 / lam3 are its flattening
-            producer = _pick_producer(dbeta_producer, N, fiber.dispersion, pm)
-            dbeta_m, ok = _grid_dbeta(lam1, grid_axes[0], grid_axes[1], fiber.dispersion, pm, producer, device)
-        else:
-            omega, ok = plan_from_wavelengths_batch(lam1, lam2, lam3)
-            dbeta_m, ok_db = compute_phase_mismatch_batch(omega, fiber.dispersion, pm)
-            ok &= ok_db
+        producer = _pick_producer(dbeta_producer, N, fiber.dispersion, pm)
+        dbeta_m, ok = _grid_dbeta(lam1, ax2, ax3, fiber.dispersion, pm, producer, shard.device, shard.lo, shard.hi)
         n_steps = n_steps_of(fiber.length_m, grid.dz_m)
         if n_steps < 1:
             raise ValueError("no steps")
+        run_kw = dict(z_max=fiber.length_m, n_steps=n_steps, save_every=cfg.save_every, check_nan=bool(cfg.check_nan),
+                      gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m, a0=a0)
     except Exception:
-        return gain, np.full(N, np.nan), None
-    idx = np.flatnonzero(ok)
-    if idx.size == 0:
-        return gain, dbeta_m, None
-    res = rk4_sweep(dbeta_m[idx], z_max=fiber.length_m, n_steps=n_steps, save_every=cfg.save_every,
-                    check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m, a0=a0, device=device)
-    gain[idx] = res.gain(p0[2], mode=gain_mode, unit=gain_unit, device=device)
-    return gain, dbeta_m, res
+        # a bad cfg fails identically on every rank (same arguments), so nobody enters the collective: the returned dbeta
+        # (which upstream is set before the run is attempted) is then produced for the whole grid by each rank itself
+        cd = None
+        if caller_dbeta is not None:
+            try:
+                cd, _ = _grid_dbeta(lam1, ax2, ax3, caller_dbeta[0], caller_dbeta[1],
+                                    _pick_producer(dbeta_producer, N, caller_dbeta[0], caller_dbeta[1]), shard.device)
+            except Exception:
+                cd = np.full(N, np.nan)
+        return gain, cd, None
+    extras = []
+    if caller_dbeta is not None:
+        try:
+            cd, _ = _grid_dbeta(lam1, ax2, ax3, caller_dbeta[0], caller_dbeta[1],
+                                _pick_producer(dbeta_producer, N, caller_dbeta[0], caller_dbeta[1]), shard.device,
+                                shard.lo, shard.hi)
+        except Exception:
+            cd = np.full(nb, np.nan)
+        extras = [cd]
+    res, ok_full, extras_full = _run_block(shard, ok, dbeta_m, extras=extras, devices=devices, **run_kw)
+    if res is not None:
+        gain[ok_full] = res.gain(p0[2], mode=gain_mode, unit=gain_unit, device=shard.device)
+    return gain, (extras_full[0] if extras_full else None), res
 
 
 def _maybe_plot(draw, save_path, show):
@@ -183,11 +299,12 @@ def plot_max_signal_gain_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m:
                                           length_unit: str = "m", return_wavelength_unit: str = "nm",
                                           gain_unit: str = "dB", xscale: str = "linear", yscale: str = "linear",
                                           show_progress: bool = True, tqdm_desc: str = "Sweeping λ3",
-                                          save_path: Optional[str] = None, show: bool = True
-                                          ) -> Tuple[np.ndarray, np.ndarray]:
+                                          save_path: Optional[str] = None, show: bool = True,
+                                          devices: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
     """Max-over-z signal gain versus lambda3 -> (x_wavelength, gain_max); NaN where a point failed.
 
     ``show_progress`` / ``tqdm_desc`` are accepted for compatibility: the sweep is a single kernel launch.
+    ``devices`` (not upstream): GPUs of this process to split the points over; under a process group the ranks split them.
     """
     lam1, lam2 = float(lambda_p1_m), float(lambda_p2_m)
     lam3, p0, ph0 = _check_sweep_inputs(lambda_signal_m, p_in, phase_in)
@@ -199,9 +316,9 @@ def plot_max_signal_gain_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1_m:
     _wavelength_axis(lam3, return_wavelength_unit)   # the reference raises this only AFTER its sweep; here before any device work
 
     # a lambda3 sweep is the 1 x N case of the grid: sweeps of 4 096 points or more get their dbeta from the device producer
-    gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
+    gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, grid_axes=(np.array([lam2]), lam3), gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
                              dispersion=dispersion, pm_cfg=phase_matching_cfg, length_unit=length_unit,
-                             gain_unit=unit, grid_axes=(np.array([lam2]), lam3), dbeta_producer="auto")
+                             gain_unit=unit, dbeta_producer="auto", devices=devices)
     x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
 
     def draw(plt):
@@ -229,7 +346,8 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
                                              yscale_gain: str = "linear", yscale_dbeta: str = "linear",
                                              show_progress: bool = True,
                                              tqdm_desc: str = "Sweeping λ3 (gain + dBeta)",
-                                             save_path: Optional[str] = None, show: bool = True
+                                             save_path: Optional[str] = None, show: bool = True,
+                                             devices: Optional[Sequence[int]] = None
                                              ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One sweep that returns both the max signal gain and dbeta(lambda3) -> (x, gain_max, dbeta).
 
@@ -250,17 +368,11 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
         method=PhaseMatchingMethod.SYMMETRIC_EVEN, max_order=4, even_orders=(2, 4), atol=0.0, rtol=1e-12)
     _wavelength_axis(lam3, return_wavelength_unit)   # validated up front (upstream: after the sweep)
 
-    # dbeta in the caller's units: per point, NaN where the plan or the mismatch is invalid (a lambda3 sweep is the 1 x N
-    # case of the grid: 4 096 points or more go through the device producer)
-    axes = (np.array([lam2]), lam3)
-    try:
-        dbeta, _ = _grid_dbeta(lam1, axes[0], axes[1], dispersion, pm_cfg, _pick_producer("auto", lam3.size, dispersion, pm_cfg), 0)
-    except Exception:
-        dbeta = np.full(lam3.shape, np.nan)
-
-    gain, _, _ = _sweep_gain(cfg=cfg, lam1=lam1, lam2=lam2, lam3=lam3, gamma=gamma, alpha=alpha, p0=p0, ph0=ph0,
-                             dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
-                             grid_axes=axes, dbeta_producer="auto")
+    # dbeta in the caller's units travels with the sweep: per point, NaN where the plan or the mismatch is invalid (a lambda3
+    # sweep is the 1 x N case of the grid: 4 096 points or more go through the device producer)
+    gain, dbeta, _ = _sweep_gain(cfg=cfg, lam1=lam1, grid_axes=(np.array([lam2]), lam3), gamma=gamma, alpha=alpha, p0=p0,
+                                 ph0=ph0, dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
+                                 dbeta_producer="auto", caller_dbeta=(dispersion, pm_cfg), devices=devices)
     gain = np.where(np.isnan(dbeta), np.nan, gain)   # a point whose dbeta failed never reaches the run upstream
     x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
     ref_line = -float(gamma) * float(p0[0] + p0[1])
@@ -290,7 +402,8 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
 def scan_dbeta_seeded_signal(*, cfg: SimulationConfig, delta_beta: Sequence[float], gamma, alpha,
                              p_in: Sequence[float], phase_in: Optional[Sequence[float]] = None,
                              length_unit: str = "m", gain_mode: GainMode = "end", gain_unit: str = "dB",
-                             dtype=np.float64, device: int = 0) -> dict:
+                             dtype=np.float64, device: Optional[int] = None,
+                             devices: Optional[Sequence[int]] = None) -> dict:
     """Scan the phase mismatch directly (PROVIDED dbeta per point) and summarise the signal gain.
 
     delta_beta: (N,) in 1/length_unit.  gamma / alpha: scalars or (N,) in per-length_unit.
@@ -308,10 +421,16 @@ def scan_dbeta_seeded_signal(*, cfg: SimulationConfig, delta_beta: Sequence[floa
                    phase_matching_cfg=PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, provided_delta_beta=0.0),
                    beta_legacy=None, length_unit=length_unit)
     scale, L, dz_m = pre["scale"], pre["fiber"].length_m, pre["grid"].dz_m
-    res = rk4_sweep(db / scale, z_max=L, dz=dz_m, save_every=cfg.save_every, check_nan=bool(cfg.check_nan),
-                    gamma=np.asarray(gamma, dtype=float) / scale, alpha=np.asarray(alpha, dtype=float) / scale,
-                    a0=make_initial_amplitudes(p0, ph0), dtype=dtype, device=device)
-    gain, bi, bg, nf = res.summary(p0[2], mode=gain_mode, unit=unit, device=device)
+    shard = _Shard(db.size, device)
+    gam, alp = np.asarray(gamma, dtype=float) / scale, np.asarray(alpha, dtype=float) / scale
+    for name, v in (("gamma", gam), ("alpha", alp)):
+        if v.ndim > 1 or (v.ndim == 1 and v.shape[0] not in (1, db.size)):
+            raise ValueError(f"{name} must be a scalar or have one entry per delta_beta point")
+    res, _, _ = _run_block(shard, np.ones(shard.hi - shard.lo, dtype=bool), shard.block(db / scale), dtype=dtype,
+                           devices=devices, z_max=L, n_steps=n_steps_of(L, dz_m), save_every=cfg.save_every,
+                           check_nan=bool(cfg.check_nan), gamma=shard.block(gam), alpha=shard.block(alp),
+                           a0=make_initial_amplitudes(p0, ph0))
+    gain, bi, bg, nf = res.summary(p0[2], mode=gain_mode, unit=unit, device=shard.device)
     secs = max(res.elapsed_ms, 1e-9) * 1e-3
     return dict(delta_beta=db, gain=gain, best_index=bi, best_delta_beta=(float(db[bi]) if bi >= 0 else float("nan")),
                 best_gain=bg, n_finite=nf, result=res, points_per_s=db.size / secs)
@@ -321,14 +440,16 @@ def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Se
                    lambda_signal_m: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
                    phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
                    phase_matching_cfg: Optional[PhaseMatchingConfig] = None, length_unit: str = "m",
-                   gain_unit: str = "dB", gain_mode: GainMode = "max", device: int = 0,
-                   dbeta_producer: str = "auto") -> dict:
+                   gain_unit: str = "dB", gain_mode: GainMode = "max", device: Optional[int] = None,
+                   dbeta_producer: str = "auto", devices: Optional[Sequence[int]] = None) -> dict:
     """Signal gain over the grid lambda_p2[Ny] x lambda_signal[Nx]: Ny*Nx independent runs, one kernel launch.
     ``dbeta_producer``: "host" (NumPy), "device" (the grid's phase mismatch computed on the GPU as well: same operations, see
     _grid_dbeta) or "auto" (device for grids of 4 096 points or more).
 
-    Row iy is exactly what ``plot_max_gain_and_dbeta_vs_lambda_signal(lambda_p2_m=lambda_p2[iy], ...)`` returns
-    (same plans, same dbeta, same NaN rules).  Returns dict(gain (Ny, Nx), dbeta (Ny, Nx) in 1/length_unit,
+    Row iy is what ``plot_max_gain_and_dbeta_vs_lambda_signal(lambda_p2_m=lambda_p2[iy], ...)`` returns (same plans, same
+    NaN rules; the same dbeta bit for bit when both calls use the same producer -- "auto" decides by the size of the whole
+    call, and the two producers differ by a few ulp on ~0.2 % of points).  ``device`` / ``devices``: one GPU,
+    or several of this process; under a ``torch.distributed`` process group the ranks split the grid.  Returns dict(gain (Ny, Nx), dbeta (Ny, Nx) in 1/length_unit,
     best_index (iy, ix) | None, best_gain, n_finite, result=SweepResult | None).
     """
     if gain_mode not in ("end", "max"):
@@ -341,16 +462,10 @@ def scan_gain_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m: Se
     if dispersion is None:
         raise ValueError("dispersion must be provided")
     pm_cfg = phase_matching_cfg if phase_matching_cfg is not None else PhaseMatchingConfig()
-    dbeta_producer = _pick_producer(dbeta_producer, lam2.size * lam3.size, dispersion, pm_cfg)
-    L2, L3 = np.meshgrid(lam2, lam3, indexing="ij")
-    l2, l3 = L2.ravel(), L3.ravel()
-    try:
-        dbeta, _ = _grid_dbeta(float(lambda_p1_m), lam2, lam3, dispersion, pm_cfg, dbeta_producer, device)
-    except Exception:
-        dbeta = np.full(l3.shape, np.nan)
-    gain, _, res = _sweep_gain(cfg=cfg, lam1=float(lambda_p1_m), lam2=l2, lam3=l3, gamma=gamma, alpha=alpha, p0=p0,
-                               ph0=ph0, dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
-                               gain_mode=gain_mode, device=device, grid_axes=(lam2, lam3), dbeta_producer=dbeta_producer)
+    gain, dbeta, res = _sweep_gain(cfg=cfg, lam1=float(lambda_p1_m), grid_axes=(lam2, lam3), gamma=gamma, alpha=alpha, p0=p0,
+                                   ph0=ph0, dispersion=dispersion, pm_cfg=pm_cfg, length_unit=length_unit, gain_unit=unit,
+                                   gain_mode=gain_mode, device=device, devices=devices, dbeta_producer=dbeta_producer,
+                                   caller_dbeta=(dispersion, pm_cfg))
     gain = np.where(np.isnan(dbeta), np.nan, gain)
     finite = np.isfinite(gain)
     best = None
@@ -366,7 +481,8 @@ def scan_six_wave_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m
                        Omega2: Sequence[float], gamma: float, alpha: float, p_in: Sequence[float],
                        phase_in: Optional[Sequence[float]] = None, dispersion: DispersionParams,
                        even_orders: Tuple[int, ...] = (2, 4), length_unit: str = "m", gain_unit: str = "dB",
-                       gain_mode: GainMode = "max", device: int = 0, dbeta_producer: str = "auto") -> dict:
+                       gain_mode: GainMode = "max", device: Optional[int] = None, dbeta_producer: str = "auto",
+                       devices: Optional[Sequence[int]] = None) -> dict:
     """Six waves [p1, p2, s1, i1, s2, i2]: pair k sits at omega_c +- Omega_k (omega_c, omega_d from the two pumps) and
     has dbeta_k = sum_{n even} beta_n (Omega_k^n - omega_d^n) 2/n!  (the symmetric-even form, dispersion.py:321-372).
     Runs the Omega1[Ny] x Omega2[Nx] grid in ONE launch of the 6-wave kernel.
@@ -402,18 +518,22 @@ def scan_six_wave_grid(*, cfg: SimulationConfig, lambda_p1_m: float, lambda_p2_m
     db1 = delta_beta_symmetric_array(wd, O1, disp_m, even_orders=even_orders)      # per metre
     db2 = delta_beta_symmetric_array(wd, O2, disp_m, even_orders=even_orders)
     dbeta_producer = _pick_producer(dbeta_producer, O1.size * O2.size, disp_m, None, even_orders=even_orders)
-    if dbeta_producer == "device":       # the whole grid's (dbeta_1, dbeta_2) from the GPU producer (psa_dbeta_pairs_f64)
+    shard = _Shard(O1.size * O2.size, device)
+    if shard.hi == shard.lo:
+        d1_blk, d2_blk = np.zeros(0), np.zeros(0)
+    elif dbeta_producer == "device":     # this block's (dbeta_1, dbeta_2) from the GPU producer (psa_dbeta_pairs_f64)
         from . import _native
-        d1_flat, d2_flat = _native.dbeta_pairs_host(_native.dbeta_model(disp_m, None, even_orders=even_orders), wd, O1, O2,
-                                                    device=device)
+        d1_blk, d2_blk = _native.dbeta_pairs_host(_native.dbeta_model(disp_m, None, even_orders=even_orders), wd, O1, O2,
+                                                  first=shard.lo, n_points=shard.hi - shard.lo, device=shard.device)
     else:
-        D1, D2 = np.meshgrid(db1, db2, indexing="ij")
-        d1_flat, d2_flat = D1.ravel(), D2.ravel()
+        i = np.arange(shard.lo, shard.hi)
+        d1_blk, d2_blk = db1[i // O2.size], db2[i % O2.size]
     from .sweep import initial_amplitudes
-    res = rk4_sweep(d1_flat, dbeta2=d2_flat, z_max=fiber.length_m, dz=grid.dz_m, save_every=cfg.save_every,
-                    check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m, alpha=fiber.alpha_1_m,
-                    a0=initial_amplitudes(p0, ph), device=device)
-    gain = res.gain(p0[2], mode=gain_mode, unit=unit, device=device)
+    res, _, _ = _run_block(shard, np.ones(shard.hi - shard.lo, dtype=bool), d1_blk, dbeta2_blk=d2_blk, n_waves=6,
+                           devices=devices, z_max=fiber.length_m, n_steps=n_steps_of(fiber.length_m, grid.dz_m),
+                           save_every=cfg.save_every, check_nan=bool(cfg.check_nan), gamma=fiber.gamma_W_m,
+                           alpha=fiber.alpha_1_m, a0=initial_amplitudes(p0, ph))
+    gain = res.gain(p0[2], mode=gain_mode, unit=unit, device=shard.device)
     shape = (O1.size, O2.size)
     return dict(gain=gain.reshape(shape), dbeta1=db1 * pre["scale"], dbeta2=db2 * pre["scale"],
                 a_end=res.a_end.reshape(shape + (6,)), first_bad_step=res.first_bad_step.reshape(shape), result=res)

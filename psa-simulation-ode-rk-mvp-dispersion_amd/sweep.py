@@ -9,7 +9,7 @@ rows, first non-finite step) written back.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -61,10 +61,50 @@ class SweepResult:
         return _native.gain_summary_host(metric, self.first_bad_step, float(p0_sig), gain_db=(u == "db"), device=device)
 
 
+def _cut(x, lo: int, hi: int, n: int, per_point_ndim: int):
+    """The [lo, hi) block of a per-point argument (leading dimension n); scalars / single rows pass through."""
+    if x is None:
+        return None
+    x = np.asarray(x)
+    return x[lo:hi] if (x.ndim == per_point_ndim and x.shape[0] == n and n > 1) else x
+
+
+def _sweep_over_devices(devices, dbeta, **kw) -> dict:
+    """One host thread per device, each integrating a contiguous block through ``psa_rk4_sweep_*(device=k)`` (ctypes
+    drops the GIL for the duration of the call; the C-ABI is thread-safe for distinct devices).  Blocks are the same
+    split the multi-process path uses (``distributed.shard_bounds``): the first ``N % len(devices)`` get one point more."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, k = int(dbeta.shape[0]), len(devices)
+    base, rem = divmod(n, k)
+    bounds, lo = [], 0
+    for r in range(k):
+        hi = lo + base + (1 if r < rem else 0)
+        bounds.append((lo, hi))
+        lo = hi
+
+    def run(r):
+        lo, hi = bounds[r]
+        if hi == lo:
+            return None
+        sub = dict(kw)
+        for name, nd in (("gamma", 1), ("alpha", 1), ("dbeta2", 1), ("a0", 2)):
+            sub[name] = _cut(kw.get(name), lo, hi, n, nd)
+        return _native.sweep_host(dbeta[lo:hi], device=int(devices[r]), **sub)
+
+    with ThreadPoolExecutor(max_workers=k) as pool:
+        parts = [p for p in pool.map(run, range(k)) if p is not None]
+    out = {key: np.concatenate([p[key] for p in parts]) for key in ("a_end", "p_end", "p_max", "first_bad_step")}
+    out["traj"] = np.concatenate([p["traj"] for p in parts]) if parts[0]["traj"] is not None else None
+    out["elapsed_ms"] = max(p["elapsed_ms"] for p in parts)
+    return out
+
+
 def rk4_sweep(dbeta, *, z_max: float, dz: Optional[float] = None, n_steps: Optional[int] = None,
               save_every: int = 10, check_nan: bool = True, gamma, alpha, a0, dbeta2=None, dtype=np.float64,
-              device: int = 0, exact_step: bool = False, want_traj: bool = False) -> SweepResult:
-    """Propagate N points.  ``dz`` gives n = int(round(z_max/dz)) as integrators.py:194; or pass ``n_steps``."""
+              device: int = 0, exact_step: bool = False, want_traj: bool = False,
+              devices: Optional[Sequence[int]] = None) -> SweepResult:
+    """Propagate N points.  ``dz`` gives n = int(round(z_max/dz)) as integrators.py:194; or pass ``n_steps``.
+    ``devices=[0, 1, ...]`` splits the points over several GPUs of this process (one thread per device)."""
     if z_max <= 0.0:
         raise ValueError("z_max must be positive")
     if n_steps is None:
@@ -75,8 +115,15 @@ def rk4_sweep(dbeta, *, z_max: float, dz: Optional[float] = None, n_steps: Optio
         raise ValueError("save_every must be a positive integer")
     if n_steps < 1:
         raise ValueError("z_max / dz rounds to zero steps")
-    r = _native.sweep_host(dbeta, n_steps=int(n_steps), z_max=float(z_max), save_every=int(save_every), gamma=gamma,
-                           alpha=alpha, a0=a0, dbeta2=dbeta2, check_nan=check_nan, exact_step=exact_step,
-                           want_traj=want_traj, dtype=dtype, device=device)
+    kw = dict(n_steps=int(n_steps), z_max=float(z_max), save_every=int(save_every), gamma=gamma, alpha=alpha, a0=a0,
+              dbeta2=dbeta2, check_nan=check_nan, exact_step=exact_step, want_traj=want_traj, dtype=dtype)
+    devs = None if devices is None else [int(d) for d in devices]
+    if devs is not None and len(devs) == 0:
+        raise ValueError("devices must name at least one GPU")
+    db = np.atleast_1d(np.asarray(dbeta))
+    if devs is not None and len(devs) > 1 and db.ndim == 1 and db.shape[0] > 1:
+        r = _sweep_over_devices(devs, db, **kw)
+    else:
+        r = _native.sweep_host(dbeta, device=(devs[0] if devs else device), **kw)
     return SweepResult(r["a_end"], r["p_end"], r["p_max"], r["first_bad_step"], int(n_steps), int(save_every),
                        r["elapsed_ms"], r["traj"])

@@ -202,12 +202,32 @@ def emit(out: dict, saved_stdout_fd: int) -> None:
     os.dup2(2, 1)
 
 
+TRAJ_VARIANTS = {
+    # name: (n_waves, dtype, points, z-steps, flags, what)
+    "c2": (4, "f64", 262_144, 400, 0, "4 waves, float64, one lane per point"),
+    "c4": (4, "f32", 524_288, 400, 0, "4 waves, float32, two points per lane (packed)"),
+    "c5": (6, "f64", 262_144, 400, 0, "6 waves, float64, one lane per point"),
+    "c2split": (4, "f64", 32_768, 3200, "split", "4 waves, float64, two lanes per point (a sweep smaller than the chip)"),
+    "c5split": (6, "f64", 32_768, 2000, "split", "6 waves, float64, two lanes per point (BASELINE config 5's shard shape)"),
+}
+
+
 def trajectory_mode(args, dev, saved_stdout_fd) -> None:
     """integrate_fixed_step's strided save with save_every = 1 (integrators.py:137-140) for a whole sweep: the one
-    regime where this path is HBM-bound (64 B per point per step, ~10 flop/B).  Single GPU."""
-    pts, nz = 262_144, 400
-    sweep = DeviceSweep(np.linspace(*DBETA_RANGE, pts), n_steps=nz, z_max=nz * 0.01, save_every=1, gamma=GAMMA,
-                        alpha=ALPHA, a0=np.sqrt(P_C2).astype(complex), check_nan=True, device=dev)
+    regime where this path is HBM-bound (16 B per wave per point per step, ~10 flop/B in float64).  Single GPU.
+    `--config c2` (default) | c4 (float32 packed) | c5 (6 waves), `--split` for the two-lane float64 layout."""
+    key = args.config + ("split" if args.split else "")
+    if key not in TRAJ_VARIANTS:
+        raise SystemExit(f"--mode trajectory: no variant {key!r} (have {sorted(TRAJ_VARIANTS)})")
+    nw, dt, pts, nz, fl, what = TRAJ_VARIANTS[key]
+    np_dtype = np.float64 if dt == "f64" else np.float32
+    p_in = P_C2 if nw == 4 else P_SIX
+    a0 = np.sqrt(p_in).astype(complex)
+    db = np.linspace(*DBETA_RANGE, pts).astype(np_dtype)
+    db2 = (0.5 * db[::-1]).astype(np_dtype) if nw == 6 else None
+    sweep = DeviceSweep(db, dbeta2_local=db2, n_steps=nz, z_max=nz * 0.01, save_every=1, gamma=GAMMA, alpha=ALPHA, a0=a0,
+                        dtype=np_dtype, check_nan=True, device=dev,
+                        extra_flags=(nat.OPT_SPLIT_POINT if fl == "split" else (nat.OPT_ONE_LANE if dt == "f64" else 0)))
     traj_bytes = sweep.enable_trajectory()
     for _ in range(args.warmup):
         sweep.launch()
@@ -224,32 +244,34 @@ def trajectory_mode(args, dev, saved_stdout_fd) -> None:
     # guard: rows of 3 points against the oracle
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    tr = sweep.traj[:, :, [0, pts // 2, pts - 1], :].cpu().numpy()       # [rows][4][3][2]
+    pick = [0, pts // 2 + 1, pts - 1]
+    tr = sweep.traj[:, :, pick, :].cpu().numpy().astype(np.float64)      # [rows][nw][3][2]
     err = 0.0
-    for j, p in enumerate((0, pts // 2, pts - 1)):
-        z, A, _ = O.integrate(np.sqrt(P_C2).astype(complex), z_max=nz * 0.01, n=nz, save_every=1, gamma=GAMMA, alpha=ALPHA,
-                              dbeta=float(np.linspace(*DBETA_RANGE, pts)[p]))
+    for j, p in enumerate(pick):
+        kw6 = {"dbeta2": float(db2[p])} if nw == 6 else {}
+        z, A, _ = O.integrate(a0, z_max=nz * 0.01, n=nz, save_every=1, gamma=GAMMA, alpha=ALPHA, dbeta=float(db[p]), **kw6)
         got = tr[:, :, j, 0] + 1j * tr[:, :, j, 1]
         err = max(err, float(np.max(np.abs(got - A) / np.abs(A))))
-    if not err < 1e-9:
+    if not err < (1e-9 if dt == "f64" else 1e-4):
         raise SystemExit(f"trajectory bench failed its parity guard: {err}")
-    facts = profile_facts().get("trajectory", {})
-    alg_bytes = traj_bytes + 96 * pts
+    facts = profile_facts().get("trajectory" if key == "c2" else "traj_" + key, {})
+    alg_bytes = traj_bytes + sweep.layout.bytes_per_point() * pts + sweep.layout.es * pts * (2 if nw == 6 else 1)
     gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
     out = {"metric": "RK4 field-point updates/sec (sweep_pts x n_fields x n_zsteps / wall_s)",
-           "value": pts * 4 * nz * args.steps / wall, "unit": "field-point updates/s", "n_gpus": 1,
+           "value": pts * nw * nz * args.steps / wall, "unit": "field-point updates/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "trajectory mode (NOT the headline config): 262144 sweep points x 4 fields x 400 z-steps, "
-                                  "float64, every step saved to HBM (save_every = 1)", "sweep_pts": pts, "n_zsteps": nz,
-                      "save_every": 1},
-           "roofline": {"kernel": facts.get("kernel", "psa::rk4_sweep_kernel<double, 4, 1, true, 256, false, true>"),
+           "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+           "config": {"workload": f"trajectory mode (NOT the headline config): {pts} sweep points x {nw} fields x {nz} z-steps, "
+                                  f"every step saved to HBM (save_every = 1); {what}", "name": "traj_" + key,
+                      "sweep_pts": pts, "n_fields": nw, "n_zsteps": nz, "save_every": 1},
+           "roofline": {"kernel": facts.get("kernel"),
                         "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": kern_ms,
                         "traffic": facts.get("hbm_bytes_per_launch"), "traffic_source": facts.get("source"),
-                        "store_only_ceiling_gbs": facts.get("store_only_ceiling_gbs"),
-                        "note": "64 B per point per saved row, coalesced 1-KiB wave stores; a kernel that does nothing but "
-                                "these stores reaches store_only_ceiling_gbs on this chip (tools/hbm_write_peak.hip)"},
+                        "store_only_ceiling_gbs": profile_facts().get("trajectory", {}).get("store_only_ceiling_gbs"),
+                        "note": "one (re, im) pair per wave per point per saved row, coalesced 1-KiB wave stores; a kernel that "
+                                "does nothing but these stores reaches store_only_ceiling_gbs on this chip "
+                                "(tools/hbm_write_peak.hip)"},
            "verify": {"trajectories_checked_vs_oracle": 3, "max_rel_err": err}}
     emit(out, saved_stdout_fd)
 
@@ -289,6 +311,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the ~15 s CPU leg (profiling runs)")
     ap.add_argument("--block64", action="store_true", help="64-thread workgroups")
     ap.add_argument("--one-lane", action="store_true", help="float64: never split a point over two lanes (A/B for c5)")
+    ap.add_argument("--split", action="store_true", help="trajectory mode: the two-lane float64 layout (32 768 points)")
     ap.add_argument("--mode", choices=["summary", "trajectory"], default="summary",
                     help="summary (default): the BASELINE workload.  trajectory: the path's HBM-bound regime -- every "
                          "step saved (save_every = 1), 262 144 points x 400 z-steps, 6.7 GB of rows per launch; reports "

@@ -19,8 +19,11 @@
  *   - "host" functions are blocking and take host pointers in NumPy layout
  *     (complex128 = interleaved re,im); "_dev" functions take device (HBM)
  *     pointers in SoA layout and are asynchronous on the given hipStream_t;
- *   - thread-safe for distinct devices/streams; no global mutable state except
- *     the per-thread error string.
+ *   - thread-safe, also for concurrent calls on one device; no global mutable state
+ *     except the per-thread error string and a mutex-protected pool of idle
+ *     per-device call contexts (stream, events, <= 64 MB of device scratch, 1 MB of
+ *     page-locked memory each) that the host-buffer entry points reuse between
+ *     calls; psa_release_cache() destroys them.
  *
  * Wave order everywhere: [pump1, pump2, signal, idler] (n_waves = 4) or
  * [pump1, pump2, signal1, idler1, signal2, idler2] (n_waves = 6, build-defined
@@ -48,6 +51,11 @@ extern "C" {
 #define PSA_E_DBETA2     -8   /* n_waves == 6 needs dbeta2; n_waves == 4 forbids it  */
 #define PSA_E_TOO_LARGE  -9   /* trajectory does not fit (int64 / device memory), or n_points exceeds the launch grid */
 #define PSA_E_DBETA_MODEL -10 /* dbeta producer: unknown method, bad even_orders / max_order / beta count  */
+#define PSA_E_FLAGS      -11  /* two options that exclude each other (SPLIT_POINT + ONE_LANE, F32_SCALAR + F32_PACKED) */
+
+/* The most points one launch takes: a launch has at most 2^32 - 1 threads in x and the two-lane float64 layout uses two
+ * per point.  (2^31 - 256 float64 records are 189 GB: a 288 GB MI355X holds them, so the limit is stated, not theoretical.) */
+#define PSA_MAX_POINTS   2147483392LL
 
 /* ---- flags ----------------------------------------------------------------- */
 /* broadcast: the array has ONE entry used for every sweep point */
@@ -83,6 +91,7 @@ int         psa_device_count(void);          /* number of visible HIP devices (0
 const char *psa_last_error(void);            /* message of the last failure on this thread            */
 const char *psa_version(void);               /* "psa-hip <semver> gfx950"                              */
 int64_t     psa_n_saved(int64_t n_steps, int32_t save_every);   /* n_steps / save_every + 1, integrators.py:115 */
+int         psa_release_cache(void);         /* destroy the idle call contexts of every device; returns how many       */
 
 /* ---- B3/B2: the sweep (host buffers, blocking) ----------------------------------
  * Replaces the body of the per-point loops scan_mismtach.py:357-392 and :694-738, i.e.
@@ -103,8 +112,9 @@ int64_t     psa_n_saved(int64_t n_steps, int32_t save_every);   /* n_steps / sav
  *   p_sig_max  [N]   max over saved rows incl. z = 0  (gain_mode "max", :38-39; NaN-propagating like np.max)
  *   first_bad_step [N]  -1, or the 0-based step index after which the state was non-finite
  *   traj_or_null   [N][n_saved][n_waves][2]  every saved row (integrators.py:137-140), or NULL.  A launch with a
- *                  trajectory takes at most 2^28 - 1 points in float64 (2^29 - 1 in float32: rows are addressed with a
- *                  32-bit lane offset) and must fit the device's free memory, else PSA_E_TOO_LARGE; the host-buffer
+ *                  trajectory takes at most 2^27 - 1 points in float64 (2^28 - 1 in float32: rows are addressed with a
+ *                  32-bit lane offset kept below 2^31; with PSA_OPT_SPLIT_POINT 2^32 / (n_waves * 16) - 1) and must fit
+ *                  the device's free memory, else PSA_E_TOO_LARGE; the host-buffer
  *                  variant moves it to the host in bounded chunks (two 256 MB staging buffers)
  *   elapsed_ms_or_null  kernel time from hipEvents on the launch stream, or NULL
  */

@@ -36,6 +36,7 @@ OPT_F32_PACKED = 1 << 13
 OPT_LOSSLESS = 1 << 14
 OPT_SPLIT_POINT = 1 << 15
 OPT_ONE_LANE = 1 << 16
+MAX_POINTS = 2**31 - 256          # PSA_MAX_POINTS: the most points one launch takes
 
 # every symbol the header declares, with (restype, argtypes)
 _P = C.c_void_p
@@ -44,6 +45,7 @@ _SIGS = {
     "psa_last_error": (C.c_char_p, []),
     "psa_version": (C.c_char_p, []),
     "psa_n_saved": (C.c_int64, [C.c_int64, C.c_int32]),
+    "psa_release_cache": (C.c_int, []),
     "psa_rk4_sweep_f64": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
                                     _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "psa_rk4_sweep_f32": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
@@ -142,6 +144,11 @@ def device_count() -> int:
 
 def version() -> str:
     return lib().psa_version().decode()
+
+
+def release_cache() -> int:
+    """Destroy the idle per-device call contexts (stream, events, scratch) the host-buffer entry points keep; -> how many."""
+    return int(lib().psa_release_cache())
 
 
 def _check(rc: int) -> None:

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "psa_internal.h"
@@ -38,19 +39,36 @@ int hip_fail(hipError_t e, const char *what) {
 
 int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max, int32_t save_every,
                     const void *dbeta, const void *dbeta2, const void *gamma, const void *alpha, const void *a0,
-                    const void *a_end, const void *p_end, const void *p_max, const void *first_bad) {
+                    const void *a_end, const void *p_end, const void *p_max, const void *first_bad, uint32_t flags,
+                    bool has_traj, size_t elem_size) {
     if (n_waves != 4 && n_waves != 6) return fail(PSA_E_NWAVES, "n_waves must be 4 or 6, got %d", n_waves);
     if (n_points < 0) return fail(PSA_E_NPOINTS, "n_points must be >= 0, got %lld", (long long)n_points);
-    // one 64-thread workgroup per wave at the finest launch shape; the grid's x extent is a 32-bit count
-    if (n_points > 64LL * 2147483647LL) return fail(PSA_E_TOO_LARGE, "n_points %lld exceeds the launch grid limit", (long long)n_points);
+    // a launch is at most 2^32 - 1 threads in x, and the two-lane float64 layout spends two of them per point
+    if (n_points > PSA_MAX_POINTS)
+        return fail(PSA_E_TOO_LARGE, "n_points %lld exceeds the launch limit of %lld points", (long long)n_points,
+                    (long long)PSA_MAX_POINTS);
     if (n_steps <= 0 || n_steps > 2147483647LL)
         return fail(PSA_E_NSTEPS, "n_steps must be in [1, 2^31), got %lld", (long long)n_steps);
     if (!(z_max > 0.0) || !std::isfinite(z_max)) return fail(PSA_E_ZMAX, "z_max must be positive");
     if (save_every <= 0) return fail(PSA_E_SAVE_EVERY, "save_every must be a positive integer");
     if (n_waves == 6 && !dbeta2 && n_points > 0) return fail(PSA_E_DBETA2, "n_waves == 6 requires dbeta2");
     if (n_waves == 4 && dbeta2) return fail(PSA_E_DBETA2, "dbeta2 must be NULL for n_waves == 4");
+    if ((flags & PSA_OPT_SPLIT_POINT) && (flags & PSA_OPT_ONE_LANE))
+        return fail(PSA_E_FLAGS, "PSA_OPT_SPLIT_POINT and PSA_OPT_ONE_LANE exclude each other");
+    if ((flags & PSA_OPT_F32_SCALAR) && (flags & PSA_OPT_F32_PACKED))
+        return fail(PSA_E_FLAGS, "PSA_OPT_F32_SCALAR and PSA_OPT_F32_PACKED exclude each other");
     if (n_points > 0 && (!dbeta || !gamma || !alpha || !a0 || !a_end || !p_end || !p_max || !first_bad))
         return fail(PSA_E_NULLPTR, "a required buffer pointer is NULL");
+    if (has_traj) {
+        // trajectory rows are addressed as a wave-uniform (row, wave) base + a 32-bit byte offset per lane, kept below 2^31
+        const unsigned long long pair = 2ull * elem_size;
+        if ((unsigned long long)n_points * pair >= (1ull << 31))
+            return fail(PSA_E_TOO_LARGE, "a trajectory launch takes at most %llu points", (1ull << 31) / pair - 1);
+        // the two-lane layout folds the lane's wave offset into that 32-bit offset
+        if ((flags & PSA_OPT_SPLIT_POINT) && (unsigned long long)n_points * n_waves * pair >= (1ull << 32))
+            return fail(PSA_E_TOO_LARGE, "a two-lane trajectory launch takes at most %llu points",
+                        (1ull << 32) / (n_waves * pair) - 1);
+    }
     return PSA_OK;
 }
 
@@ -115,12 +133,9 @@ int sweep_dev(void *stream, int n_waves, int64_t n_points, int64_t n_steps, doub
               const T *d_dbeta, const T *d_dbeta2, const T *d_gamma, const T *d_alpha, const T *d_a0_soa,
               uint32_t flags, T *d_a_end_soa, T *d_p_end, T *d_p_max, int64_t *d_first_bad, T *d_traj_soa) {
     int rc = validate_common(n_waves, n_points, n_steps, z_max, save_every, d_dbeta, d_dbeta2, d_gamma, d_alpha,
-                             d_a0_soa, d_a_end_soa, d_p_end, d_p_max, d_first_bad);
+                             d_a0_soa, d_a_end_soa, d_p_end, d_p_max, d_first_bad, flags, d_traj_soa != nullptr, sizeof(T));
     if (rc != PSA_OK) return rc;
     if (n_points == 0) return PSA_OK;
-    // trajectory rows are addressed as (row, wave) base + a 32-bit byte offset per lane
-    if (d_traj_soa && (unsigned long long)n_points * (2 * sizeof(T)) >= (1ull << 32))
-        return fail(PSA_E_TOO_LARGE, "a trajectory launch takes at most %llu points", (1ull << 32) / (2 * sizeof(T)) - 1);
     auto a = make_args<T>(n_waves, n_points, n_steps, z_max, save_every, d_dbeta, d_dbeta2, d_gamma, d_alpha,
                           d_a0_soa, flags, d_a_end_soa, d_p_end, d_p_max, d_first_bad, d_traj_soa);
     hipError_t e = Launch<T>::sweep((hipStream_t)stream, n_waves, check_mode(flags), (flags & PSA_OPT_LDS_STAGING) != 0,
@@ -135,20 +150,6 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
     template <typename U> U *as() { return (U *)p; }
-};
-
-// The dozen small per-sweep buffers of the host-buffer API come out of ONE allocation (256-B aligned slices): a single-point
-// run (BASELINE config 1) otherwise spends as long in hipMalloc / hipFree as a tenth of its kernel.
-struct DevArena {
-    DevBuf buf;
-    size_t used = 0, cap = 0;
-    static size_t aligned(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-    hipError_t reserve(size_t bytes) { cap = bytes; return buf.alloc(bytes); }
-    template <typename U> U *take(size_t count) {
-        U *p = (U *)((char *)buf.p + used);
-        used += aligned(count * sizeof(U));
-        return p;
-    }
 };
 
 // Makes `device` current for the scope of a host-buffer entry point and puts the caller's device back afterwards
@@ -175,15 +176,126 @@ int check_device(int device, const char *what) {
     return PSA_OK;
 }
 
+// ---- host-call contexts ------------------------------------------------------------------------------------------
+// What a host-buffer sweep needs besides its buffers -- a stream, two timing events, (for trajectories of more than one
+// point) two copy streams and an event, device scratch and a page-locked mirror for small transfers -- is created once per
+// concurrent caller and device and kept in a pool: the reference's own scenarios are sweeps of 1, 30 and 100 points
+// (main.py), where creating and destroying these per call cost as much as a tenth of the kernel (0.5-0.75 ms of a 4-5 ms
+// single run).  A context is leased to one call at a time (concurrent callers on one device each get their own), its
+// streams are drained before it goes back, and psa_release_cache() destroys the idle ones.
+constexpr size_t CTX_ARENA_KEEP = 64u << 20;     // device scratch larger than this is allocated per call, not kept
+constexpr size_t CTX_PINNED_IN = 256u << 10;     // page-locked mirror: inputs ...
+constexpr size_t CTX_PINNED_OUT = 768u << 10;    // ... and outputs of a small sweep travel in ONE copy each way
+
+struct HostCtx {
+    int device = -1;
+    hipStream_t st = nullptr, st_copy[2] = {nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_kernel = nullptr;
+    void *arena = nullptr;
+    size_t arena_cap = 0;
+    char *pinned = nullptr;
+
+    hipError_t init(int dev) {
+        device = dev;
+        hipError_t e;
+        if ((e = hipStreamCreate(&st)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&ev0)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&ev1)) != hipSuccess) return e;
+        return hipHostMalloc((void **)&pinned, CTX_PINNED_IN + CTX_PINNED_OUT, hipHostMallocDefault);
+    }
+    hipError_t need_copy_streams() {
+        hipError_t e;
+        for (int b = 0; b < 2; ++b)
+            if (!st_copy[b] && (e = hipStreamCreate(&st_copy[b])) != hipSuccess) return e;
+        if (!ev_kernel && (e = hipEventCreateWithFlags(&ev_kernel, hipEventDisableTiming)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    hipError_t need_arena(size_t bytes) {   // grow-only; the caller has checked bytes <= CTX_ARENA_KEEP
+        if (bytes <= arena_cap) return hipSuccess;
+        if (arena) { (void)hipFree(arena); arena = nullptr; arena_cap = 0; }
+        size_t cap = 1u << 20;
+        while (cap < bytes) cap <<= 1;
+        hipError_t e = hipMalloc(&arena, cap);
+        if (e == hipSuccess) arena_cap = cap;
+        return e;
+    }
+    void drain() {
+        for (int b = 0; b < 2; ++b) if (st_copy[b]) (void)hipStreamSynchronize(st_copy[b]);
+        if (st) (void)hipStreamSynchronize(st);
+    }
+    void destroy() {   // its device must be current
+        drain();
+        for (int b = 0; b < 2; ++b) if (st_copy[b]) (void)hipStreamDestroy(st_copy[b]);
+        if (ev_kernel) (void)hipEventDestroy(ev_kernel);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (st) (void)hipStreamDestroy(st);
+        if (arena) (void)hipFree(arena);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+};
+
+std::mutex g_ctx_mutex;
+std::vector<HostCtx *> g_ctx_idle;
+
+// Lease of one context for the scope of a call; the device must already be current (DeviceScope) and stays so until the
+// lease has ended (declare the lease AFTER the scope and after any per-call DevBuf: it drains the streams first).
+struct CtxLease {
+    HostCtx *c = nullptr;
+    hipError_t acquire(int device) {
+        {
+            std::lock_guard<std::mutex> lock(g_ctx_mutex);
+            for (size_t i = 0; i < g_ctx_idle.size(); ++i)
+                if (g_ctx_idle[i]->device == device) {
+                    c = g_ctx_idle[i];
+                    g_ctx_idle.erase(g_ctx_idle.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        c = new HostCtx();
+        hipError_t e = c->init(device);
+        if (e != hipSuccess) {
+            c->destroy();
+            delete c;
+            c = nullptr;
+        }
+        return e;
+    }
+    ~CtxLease() {
+        if (!c) return;
+        c->drain();   // nothing of this call may still be in flight when the buffers are reused or freed
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_ctx_idle.push_back(c);
+    }
+};
+
+// 256-B aligned slices of one allocation
+struct Carver {
+    char *base = nullptr;
+    size_t used = 0;
+    static size_t aligned(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <typename U> U *take(size_t count) {
+        U *p = (U *)(base + used);
+        used += aligned(count * sizeof(U));
+        return p;
+    }
+};
+
 // staging for the trajectory transpose of the host-buffer API: two buffers of at most this many bytes each
 constexpr size_t TRAJ_STAGE_BYTES = 256u << 20;
+
+#define HIP_RET(expr)                                                \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);            \
+    } while (0)
 
 template <typename T>
 int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max, int32_t save_every,
                const T *dbeta, const T *dbeta2, const T *gamma, const T *alpha, const T *a0, uint32_t flags,
                T *a_end, T *p_end, T *p_max, int64_t *first_bad, T *traj, double *elapsed_ms) {
     int rc = validate_common(n_waves, n_points, n_steps, z_max, save_every, dbeta, dbeta2, gamma, alpha, a0, a_end,
-                             p_end, p_max, first_bad);
+                             p_end, p_max, first_bad, flags, traj != nullptr, sizeof(T));
     if (rc != PSA_OK) return rc;
     if (elapsed_ms) *elapsed_ms = 0.0;
     if (n_points == 0) return PSA_OK;
@@ -214,111 +326,146 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
         if (chunk_pts < 32) chunk_pts = 32;                                // (very long single runs: one tile per chunk)
         if (chunk_pts > N) chunk_pts = N;
     }
+    const size_t traj_bytes = traj_elems * sizeof(T);
+    const size_t stage_bytes = chunk_pts * point_bytes;
+
+    // -- layout of the call's device scratch: [inputs] [device-only] [outputs (+ the one-point trajectory)] [trajectory] [staging]
+    using C = Carver;
+    const size_t in_bytes = C::aligned(N * sizeof(T)) * (dbeta2 ? 2 : 1) + C::aligned(n_gamma * sizeof(T)) +
+                            C::aligned(n_alpha * sizeof(T)) + C::aligned(n_a0 * nc * sizeof(T));
+    const size_t mid_bytes = C::aligned(n_a0 * nc * sizeof(T)) + C::aligned(N * nc * sizeof(T));
+    const bool traj_in_out = traj && N == 1;     // [rows][nw][1] and [1][rows][nw] coincide: it leaves with the outputs
+    const size_t out_bytes = C::aligned(N * nc * sizeof(T)) + 2 * C::aligned(N * sizeof(T)) + C::aligned(N * sizeof(int64_t)) +
+                             (traj_in_out ? C::aligned(traj_bytes) : 0);
+    const size_t small_total = in_bytes + mid_bytes + out_bytes;
+    const size_t traj_total = (traj && !traj_in_out) ? C::aligned(traj_bytes) + 2 * C::aligned(stage_bytes) : 0;
 
     DeviceScope scope;
-    DevArena arena;
-    DevBuf b_traj_soa, b_stage[2];
-    T *d_dbeta = nullptr, *d_dbeta2 = nullptr, *d_gamma = nullptr, *d_alpha = nullptr, *d_a0_aos = nullptr, *d_a0_soa = nullptr,
-      *d_aend_soa = nullptr, *d_aend_aos = nullptr, *d_pend = nullptr, *d_pmax = nullptr;
-    int64_t *d_bad = nullptr;
-    hipStream_t st = nullptr, st_copy[2] = {nullptr, nullptr};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_kernel = nullptr;
-
-    HIP_TRY(scope.enter(device));
+    DevBuf b_small, b_traj;                      // per-call allocations when the cached scratch is not used
+    CtxLease lease;
+    HIP_RET(scope.enter(device));
     if (traj) {   // say "too large" before hipMalloc says "out of memory"
         size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const long double need = (long double)traj_elems * sizeof(T) + 2.0L * (long double)chunk_pts * point_bytes
-                                 + (long double)N * (3 * nc + 4) * sizeof(T);
-        if (need > (long double)free_b) {
-            rc = fail(PSA_E_TOO_LARGE, "trajectory of %.3g GB does not fit the %.3g GB free on device %d",
-                      (double)(need / 1e9L), (double)free_b / 1e9, device);
-            goto done;
+        HIP_RET(hipMemGetInfo(&free_b, &total_b));
+        const long double need = (long double)small_total + (long double)traj_total;
+        if (need > (long double)CTX_ARENA_KEEP && need > (long double)free_b)
+            return fail(PSA_E_TOO_LARGE, "trajectory of %.3g GB does not fit the %.3g GB free on device %d",
+                        (double)(need / 1e9L), (double)free_b / 1e9, device);
+    }
+    HIP_RET(lease.acquire(device));
+    HostCtx &cx = *lease.c;
+    hipStream_t st = cx.st;
+
+    Carver small, big;
+    const bool keep_all = small_total + traj_total <= CTX_ARENA_KEEP;
+    if (keep_all) {
+        HIP_RET(cx.need_arena(small_total + traj_total));
+        small.base = (char *)cx.arena;
+        big.base = (char *)cx.arena + small_total;
+    } else {
+        if (small_total <= CTX_ARENA_KEEP) {
+            HIP_RET(cx.need_arena(small_total));
+            small.base = (char *)cx.arena;
+        } else {
+            HIP_RET(b_small.alloc(small_total));
+            small.base = (char *)b_small.p;
+        }
+        if (traj_total) {
+            HIP_RET(b_traj.alloc(traj_total));
+            big.base = (char *)b_traj.p;
         }
     }
-    HIP_TRY(hipStreamCreate(&st));
-    {
-        using A = DevArena;
-        const size_t total = A::aligned(N * sizeof(T)) * (dbeta2 ? 2 : 1) + A::aligned(n_gamma * sizeof(T)) +
-                             A::aligned(n_alpha * sizeof(T)) + 2 * A::aligned(n_a0 * nc * sizeof(T)) +
-                             2 * A::aligned(N * nc * sizeof(T)) + 2 * A::aligned(N * sizeof(T)) + A::aligned(N * sizeof(int64_t));
-        HIP_TRY(arena.reserve(total));
-        d_dbeta = arena.take<T>(N);
-        if (dbeta2) d_dbeta2 = arena.take<T>(N);
-        d_gamma = arena.take<T>(n_gamma);
-        d_alpha = arena.take<T>(n_alpha);
-        d_a0_aos = arena.take<T>(n_a0 * nc);
-        d_a0_soa = arena.take<T>(n_a0 * nc);
-        d_aend_soa = arena.take<T>(N * nc);
-        d_aend_aos = arena.take<T>(N * nc);
-        d_pend = arena.take<T>(N);
-        d_pmax = arena.take<T>(N);
-        d_bad = arena.take<int64_t>(N);
-    }
-    if (traj) HIP_TRY(b_traj_soa.alloc(traj_elems * sizeof(T)));
-    HIP_TRY(hipMemcpyAsync(d_dbeta, dbeta, N * sizeof(T), hipMemcpyHostToDevice, st));
-    if (dbeta2) HIP_TRY(hipMemcpyAsync(d_dbeta2, dbeta2, N * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_gamma, gamma, n_gamma * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_alpha, alpha, n_alpha * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_a0_aos, a0, n_a0 * nc * sizeof(T), hipMemcpyHostToDevice, st));
-    HIP_TRY(Launch<T>::a2s(st, d_a0_aos, d_a0_soa, (long long)n_a0, nc));
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventRecord(ev0, st));
-    rc = sweep_dev<T>(st, n_waves, n_points, n_steps, z_max, save_every, d_dbeta,
-                      d_dbeta2, d_gamma, d_alpha, d_a0_soa, flags,
-                      d_aend_soa, d_pend, d_pmax, d_bad,
-                      traj ? b_traj_soa.as<T>() : nullptr);
-    if (rc != PSA_OK) goto done;
-    HIP_TRY(hipEventRecord(ev1, st));
-    HIP_TRY(Launch<T>::s2a(st, d_aend_soa, d_aend_aos, (long long)N, nc));
-    HIP_TRY(hipMemcpyAsync(a_end, d_aend_aos, N * nc * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p_end, d_pend, N * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p_max, d_pmax, N * sizeof(T), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(first_bad, d_bad, N * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    if (traj && N == 1) {   // [rows][nw][1] and [1][rows][nw] coincide
-        HIP_TRY(hipMemcpyAsync(traj, b_traj_soa.p, traj_elems * sizeof(T), hipMemcpyDeviceToHost, st));
+    T *d_dbeta = small.take<T>(N);
+    T *d_dbeta2 = dbeta2 ? small.take<T>(N) : nullptr;
+    T *d_gamma = small.take<T>(n_gamma);
+    T *d_alpha = small.take<T>(n_alpha);
+    T *d_a0_aos = small.take<T>(n_a0 * nc);
+    T *d_a0_soa = small.take<T>(n_a0 * nc);
+    T *d_aend_soa = small.take<T>(N * nc);
+    const size_t out_off = small.used;
+    T *d_aend_aos = small.take<T>(N * nc);
+    T *d_pend = small.take<T>(N);
+    T *d_pmax = small.take<T>(N);
+    int64_t *d_bad = small.take<int64_t>(N);
+    T *d_traj = nullptr, *d_stage[2] = {nullptr, nullptr};
+    if (traj_in_out) {
+        d_traj = small.take<T>(traj_elems);
     } else if (traj) {
-        HIP_TRY(hipEventCreateWithFlags(&ev_kernel, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev_kernel, st));
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(b_stage[b].alloc(chunk_pts * point_bytes));
-            HIP_TRY(hipStreamCreate(&st_copy[b]));
-            HIP_TRY(hipStreamWaitEvent(st_copy[b], ev_kernel, 0));
-        }
+        d_traj = big.take<T>(traj_elems);
+        d_stage[0] = (T *)big.take<char>(stage_bytes);
+        d_stage[1] = (T *)big.take<char>(stage_bytes);
+    }
+
+    // -- inputs: a small sweep's arrive in ONE copy from the page-locked mirror (same slice offsets as on the device)
+    const bool mirror = in_bytes <= CTX_PINNED_IN && out_bytes <= CTX_PINNED_OUT;
+    if (mirror) {
+        char *m = cx.pinned;
+        auto put = [&](const T *dev, const T *src, size_t count) {
+            std::memcpy(m + ((const char *)dev - small.base), src, count * sizeof(T));
+        };
+        put(d_dbeta, dbeta, N);
+        if (dbeta2) put(d_dbeta2, dbeta2, N);
+        put(d_gamma, gamma, n_gamma);
+        put(d_alpha, alpha, n_alpha);
+        put(d_a0_aos, a0, n_a0 * nc);
+        HIP_RET(hipMemcpyAsync(small.base, m, in_bytes, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_RET(hipMemcpyAsync(d_dbeta, dbeta, N * sizeof(T), hipMemcpyHostToDevice, st));
+        if (dbeta2) HIP_RET(hipMemcpyAsync(d_dbeta2, dbeta2, N * sizeof(T), hipMemcpyHostToDevice, st));
+        HIP_RET(hipMemcpyAsync(d_gamma, gamma, n_gamma * sizeof(T), hipMemcpyHostToDevice, st));
+        HIP_RET(hipMemcpyAsync(d_alpha, alpha, n_alpha * sizeof(T), hipMemcpyHostToDevice, st));
+        HIP_RET(hipMemcpyAsync(d_a0_aos, a0, n_a0 * nc * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    HIP_RET(Launch<T>::a2s(st, d_a0_aos, d_a0_soa, (long long)n_a0, nc));
+    HIP_RET(hipEventRecord(cx.ev0, st));
+    rc = sweep_dev<T>(st, n_waves, n_points, n_steps, z_max, save_every, d_dbeta, d_dbeta2, d_gamma, d_alpha, d_a0_soa,
+                      flags, d_aend_soa, d_pend, d_pmax, d_bad, d_traj);
+    if (rc != PSA_OK) return rc;
+    HIP_RET(hipEventRecord(cx.ev1, st));
+    HIP_RET(Launch<T>::s2a(st, d_aend_soa, d_aend_aos, (long long)N, nc));
+    if (mirror) {
+        HIP_RET(hipMemcpyAsync(cx.pinned + CTX_PINNED_IN, small.base + out_off, out_bytes, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_RET(hipMemcpyAsync(a_end, d_aend_aos, N * nc * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIP_RET(hipMemcpyAsync(p_end, d_pend, N * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIP_RET(hipMemcpyAsync(p_max, d_pmax, N * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIP_RET(hipMemcpyAsync(first_bad, d_bad, N * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (traj_in_out) HIP_RET(hipMemcpyAsync(traj, d_traj, traj_bytes, hipMemcpyDeviceToHost, st));
+    }
+    if (traj && !traj_in_out) {
+        HIP_RET(cx.need_copy_streams());
+        HIP_RET(hipEventRecord(cx.ev_kernel, st));
+        for (int b = 0; b < 2; ++b) HIP_RET(hipStreamWaitEvent(cx.st_copy[b], cx.ev_kernel, 0));
         int b = 0;
         for (size_t p0 = 0; p0 < N; p0 += chunk_pts, b ^= 1) {
             const size_t pts = (N - p0 < chunk_pts) ? N - p0 : chunk_pts;
             // stream order on st_copy[b] keeps the staging buffer busy until its previous copy has finished
-            HIP_TRY(Launch<T>::t2a(st_copy[b], b_traj_soa.as<T>() + 2 * p0, b_stage[b].as<T>(), (long long)pts,
-                                   (long long)N, (long long)n_saved, nc));
-            HIP_TRY(hipMemcpyAsync(traj + p0 * (size_t)n_saved * nc, b_stage[b].p, pts * point_bytes,
-                                   hipMemcpyDeviceToHost, st_copy[b]));
+            HIP_RET(Launch<T>::t2a(cx.st_copy[b], d_traj + 2 * p0, d_stage[b], (long long)pts, (long long)N,
+                                   (long long)n_saved, nc));
+            HIP_RET(hipMemcpyAsync(traj + p0 * (size_t)n_saved * nc, d_stage[b], pts * point_bytes, hipMemcpyDeviceToHost,
+                                   cx.st_copy[b]));
         }
-        HIP_TRY(hipStreamSynchronize(st_copy[0]));
-        HIP_TRY(hipStreamSynchronize(st_copy[1]));
+        HIP_RET(hipStreamSynchronize(cx.st_copy[0]));
+        HIP_RET(hipStreamSynchronize(cx.st_copy[1]));
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_RET(hipStreamSynchronize(st));
+    if (mirror) {
+        const char *m = cx.pinned + CTX_PINNED_IN;
+        auto get = [&](void *dst, const void *dev, size_t bytes) {
+            std::memcpy(dst, m + ((const char *)dev - (small.base + out_off)), bytes);
+        };
+        get(a_end, d_aend_aos, N * nc * sizeof(T));
+        get(p_end, d_pend, N * sizeof(T));
+        get(p_max, d_pmax, N * sizeof(T));
+        get(first_bad, d_bad, N * sizeof(int64_t));
+        if (traj_in_out) get(traj, d_traj, traj_bytes);
+    }
     if (elapsed_ms) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        HIP_RET(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
         *elapsed_ms = (double)ms;
     }
-done:
-    for (int b = 0; b < 2; ++b) {
-        if (st_copy[b]) {
-            (void)hipStreamSynchronize(st_copy[b]);
-            (void)hipStreamDestroy(st_copy[b]);
-        }
-    }
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (ev_kernel) (void)hipEventDestroy(ev_kernel);
-    if (st) {
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamDestroy(st);
-    }
-    return rc;
+    return PSA_OK;
 }
 
 template <typename T> struct GainLaunch;
@@ -346,25 +493,59 @@ int gain_summary_host(int device, int64_t n, const T *p_metric, const int64_t *f
     int rc = check_device(device, "the gain summary");
     if (rc != PSA_OK) return rc;
     const size_t N = (size_t)n;
+    using C = Carver;
+    // [inputs: p, first_bad] [workspace] [outputs: gain, (best_index, best_gain, n_finite)]
+    const size_t in_bytes = C::aligned(N * sizeof(T)) + (first_bad ? C::aligned(N * 8) : 0);
+    const size_t ws_bytes = C::aligned((size_t)psa::gain_summary_workspace_bytes(n));
+    const size_t out_bytes = (gain_out ? C::aligned(N * sizeof(T)) : 0) + C::aligned(3 * 8);
+    const size_t total = in_bytes + ws_bytes + out_bytes;
     DeviceScope scope;
-    DevBuf bp, bb, bg, bi, bbg, bn, bw;
-    HIP_TRY(scope.enter(device));
-    HIP_TRY(bp.alloc(N * sizeof(T)));
-    if (first_bad) HIP_TRY(bb.alloc(N * 8));
-    if (gain_out) HIP_TRY(bg.alloc(N * sizeof(T)));
-    HIP_TRY(bi.alloc(8)); HIP_TRY(bbg.alloc(8)); HIP_TRY(bn.alloc(8));
-    HIP_TRY(bw.alloc((size_t)psa::gain_summary_workspace_bytes(n)));
-    if (N) HIP_TRY(hipMemcpy(bp.p, p_metric, N * sizeof(T), hipMemcpyHostToDevice));
-    if (first_bad && N) HIP_TRY(hipMemcpy(bb.p, first_bad, N * 8, hipMemcpyHostToDevice));
-    rc = gain_summary_dev<T>(nullptr, n, bp.as<T>(), first_bad ? bb.as<int64_t>() : nullptr, p0_sig, gain_db,
-                             gain_out ? bg.as<T>() : nullptr, bi.as<int64_t>(), bbg.as<double>(), bn.as<int64_t>(), bw.p);
-    if (rc != PSA_OK) goto done;
-    if (gain_out && N) HIP_TRY(hipMemcpy(gain_out, bg.p, N * sizeof(T), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(best_index, bi.p, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(best_gain, bbg.p, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(n_finite, bn.p, 8, hipMemcpyDeviceToHost));
-done:
-    return rc;
+    DevBuf b_all;
+    CtxLease lease;
+    HIP_RET(scope.enter(device));
+    HIP_RET(lease.acquire(device));
+    HostCtx &cx = *lease.c;
+    Carver cv;
+    if (total <= CTX_ARENA_KEEP) {
+        HIP_RET(cx.need_arena(total));
+        cv.base = (char *)cx.arena;
+    } else {
+        HIP_RET(b_all.alloc(total));
+        cv.base = (char *)b_all.p;
+    }
+    T *d_p = cv.take<T>(N);
+    int64_t *d_bad = first_bad ? cv.take<int64_t>(N) : nullptr;
+    void *d_ws = cv.take<char>(ws_bytes);
+    const size_t out_off = cv.used;
+    T *d_gain = gain_out ? cv.take<T>(N) : nullptr;
+    int64_t *d_scal = cv.take<int64_t>(3);          // best_index | best_gain (double) | n_finite
+    const bool mirror = in_bytes <= CTX_PINNED_IN && out_bytes <= CTX_PINNED_OUT;
+    if (mirror) {
+        if (N) std::memcpy(cx.pinned, p_metric, N * sizeof(T));
+        if (first_bad && N) std::memcpy(cx.pinned + ((char *)d_bad - cv.base), first_bad, N * 8);
+        if (N) HIP_RET(hipMemcpyAsync(cv.base, cx.pinned, in_bytes, hipMemcpyHostToDevice, cx.st));
+    } else {
+        HIP_RET(hipMemcpyAsync(d_p, p_metric, N * sizeof(T), hipMemcpyHostToDevice, cx.st));
+        if (first_bad) HIP_RET(hipMemcpyAsync(d_bad, first_bad, N * 8, hipMemcpyHostToDevice, cx.st));
+    }
+    rc = gain_summary_dev<T>(cx.st, n, d_p, d_bad, p0_sig, gain_db, d_gain, d_scal, (double *)(d_scal + 1), d_scal + 2, d_ws);
+    if (rc != PSA_OK) return rc;
+    int64_t scal[3];
+    if (mirror) {
+        char *m = cx.pinned + CTX_PINNED_IN;
+        HIP_RET(hipMemcpyAsync(m, cv.base + out_off, out_bytes, hipMemcpyDeviceToHost, cx.st));
+        HIP_RET(hipStreamSynchronize(cx.st));
+        if (gain_out && N) std::memcpy(gain_out, m, N * sizeof(T));
+        std::memcpy(scal, m + ((char *)d_scal - (cv.base + out_off)), sizeof(scal));
+    } else {
+        if (gain_out && N) HIP_RET(hipMemcpyAsync(gain_out, d_gain, N * sizeof(T), hipMemcpyDeviceToHost, cx.st));
+        HIP_RET(hipMemcpyAsync(scal, d_scal, sizeof(scal), hipMemcpyDeviceToHost, cx.st));
+        HIP_RET(hipStreamSynchronize(cx.st));
+    }
+    *best_index = scal[0];
+    std::memcpy(best_gain, &scal[1], 8);
+    *n_finite = scal[2];
+    return PSA_OK;
 }
 
 // dbeta producer: argument checks + the model struct shared by both kernels
@@ -449,10 +630,25 @@ int psa_device_count(void) {
     return n;
 }
 const char *psa_last_error(void) { return g_err; }
-const char *psa_version(void) { return "psa-hip 0.2.0 gfx950"; }
+const char *psa_version(void) { return "psa-hip 0.3.0 gfx950"; }
 int64_t psa_n_saved(int64_t n_steps, int32_t save_every) {
     if (n_steps < 0 || save_every <= 0) return -1;
     return n_steps / save_every + 1;
+}
+int psa_release_cache(void) {
+    std::vector<HostCtx *> idle;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        idle.swap(g_ctx_idle);
+    }
+    int prev = -1;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (HostCtx *c : idle) {
+        if (hipSetDevice(c->device) == hipSuccess) c->destroy();
+        delete c;
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    return (int)idle.size();
 }
 
 int psa_rk4_sweep_f64(int device, int n_waves, int64_t n_points, int64_t n_steps, double z_max, int32_t save_every,

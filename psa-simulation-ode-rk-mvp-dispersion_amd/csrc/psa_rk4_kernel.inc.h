@@ -44,6 +44,11 @@ __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned 
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<float>::type v) {
     asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+// two adjacent float32 points' (re, im) pairs in one 16-B store (the packed kernel: points 2i and 2i+1 share a lane)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_quad_nt(const void *sbase, const unsigned voff, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 
 // cos/sin of a float64 phase, delivered in the working precision.
 template <typename T> struct Phase;

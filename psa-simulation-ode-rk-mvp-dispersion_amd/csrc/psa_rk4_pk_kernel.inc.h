@@ -27,20 +27,32 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     if (pt[0] >= N) return;
     const bool live1 = 2 * idx + 1 < N;  // slot 1 holds a real point (else computed but never stored)
 
+    // wave-uniform: every lane of this wave holds two real points -> 8-B loads / stores of the adjacent pair, 16-B trajectory
+    // stores; the (at most one) wave with the odd tail or past-the-end lanes takes the element-wise path
+    const bool wave_full = __builtin_amdgcn_readfirstlane((int)(2 * (idx | 63) + 1 < N)) != 0;
+    typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));   // an 8-B access at float alignment (odd N rows)
+    auto load2 = [&](const float *base, const int stride) -> V {   // base[pt0 * stride], base[pt1 * stride]
+        if (stride == 0) return splat2(base[0]);
+        if (wave_full) return *reinterpret_cast<const f32x2_u *>(base + pt[0]);
+        return (V){base[pt[0]], base[pt[1]]};
+    };
+
     V y[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float *row = A.a0 + (long long)c * A.a0_ld;
-        y[c] = (V){row[pt[0] * A.a0_stride], row[pt[1] * A.a0_stride]};
-    }
-    const V g = (V){A.gamma[pt[0] * A.gamma_stride], A.gamma[pt[1] * A.gamma_stride]};
+    for (int c = 0; c < NC; ++c) y[c] = load2(A.a0 + (long long)c * A.a0_ld, A.a0_stride);
+    const V g = load2(A.gamma, A.gamma_stride);
     const V tg = g + g;
-    const V ha = splat2(-0.5f) * (V){A.alpha[pt[0] * A.alpha_stride], A.alpha[pt[1] * A.alpha_stride]};
+    const V ha = splat2(-0.5f) * load2(A.alpha, A.alpha_stride);
     double dbd[NP][2];
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        dbd[0][w] = (double)A.dbeta[pt[w]];
-        if constexpr (NP == 2) dbd[1][w] = (double)A.dbeta2[pt[w]];
+    {
+        const V d0 = load2(A.dbeta, 1);
+        dbd[0][0] = (double)d0.x;
+        dbd[0][1] = (double)d0.y;
+        if constexpr (NP == 2) {
+            const V d1 = load2(A.dbeta2, 1);
+            dbd[1][0] = (double)d1.x;
+            dbd[1][1] = (double)d1.y;
+        }
     }
     const double hd = A.z_max / (double)A.n_steps;
     const V h = splat2((float)hd), hh = splat2((float)(0.5 * hd)), h6 = splat2((float)(hd / 6.0));
@@ -77,20 +89,42 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     auto store_rows = [&](float *base) {  // base[c * N + point]
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            base[(long long)c * N + pt[0]] = y[c].x;
-            if (live1) base[(long long)c * N + pt[1]] = y[c].y;
+            float *dst = base + (long long)c * N + pt[0];
+            if (wave_full) {
+                *reinterpret_cast<f32x2_u *>(dst) = y[c];
+            } else {
+                dst[0] = y[c].x;
+                if (live1) dst[1] = y[c].y;
+            }
+        }
+    };
+    auto store2 = [&](float *base, const V v) {   // base[pt0], base[pt1]
+        if (wave_full) {
+            *reinterpret_cast<f32x2_u *>(base + pt[0]) = v;
+        } else {
+            base[pt[0]] = v.x;
+            if (live1) base[pt[1]] = v.y;
         }
     };
 
     const int se = A.save_every;
     const int n_rows = A.n_steps / se;
     const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;
-    auto store_traj_row = [&](const int r) {  // [row][wave][N][2]: one (re, im) pair per point
-        f32x2 *dst = reinterpret_cast<f32x2 *>(A.traj) + (long long)r * NW * N;
+    // trajectory rows [row][wave][N][2]: the lane's two points are adjacent, so each wave of the model is ONE 16-B streaming
+    // store per lane (1 KiB per wave instruction); the (row, wave) part of the address stays in SGPRs and the lane adds a
+    // 32-bit byte offset (the C-ABI keeps N * 8 B < 2^31 for trajectory launches), exactly as rk4_sweep_kernel does.
+    const unsigned lane_off = (unsigned)idx * 16u;
+    auto store_traj_row = [&](const int r) {
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * 8;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            dst[(long long)j * N + pt[0]] = (f32x2){y[2 * j].x, y[2 * j + 1].x};
-            if (live1) dst[(long long)j * N + pt[1]] = (f32x2){y[2 * j].y, y[2 * j + 1].y};
+            const char *wb = rowb + (long long)j * N * 8;
+            if (wave_full) {
+                store_quad_nt(wb, lane_off, (f32x4){y[2 * j].x, y[2 * j + 1].x, y[2 * j].y, y[2 * j + 1].y});
+            } else {
+                store_pair_nt(wb, lane_off, (f32x2){y[2 * j].x, y[2 * j + 1].x});
+                if (live1) store_pair_nt(wb, lane_off + 8u, (f32x2){y[2 * j].y, y[2 * j + 1].y});
+            }
         }
     };
     if constexpr (TRAJ) store_traj_row(0);
@@ -123,6 +157,48 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
         }
         if constexpr (CHECK == CHECK_EXACT) track(step_index);
     };
+
+    auto write_summary = [&]() {
+        store2(A.p_end, pe);
+        store2(A.p_max, pm);
+        A.first_bad[pt[0]] = bad[0];
+        if (live1) A.first_bad[pt[1]] = bad[1];
+    };
+
+    // ---- save_every == 1 with a trajectory: every step is a saved row (integrators.py:137) -- the HBM-bound regime.  A
+    // dedicated loop, as in rk4_sweep_kernel: per row only |A_sig|^2, the running maximum, the block-mode finite test and
+    // the NW streaming stores; two steps per trip so one row's stores issue under the next step.
+    if constexpr (TRAJ) {
+        if (se == 1) {
+            auto save_row = [&](const int r) {
+                pe = fma_(y[4], y[4], y[5] * y[5]);
+                pm = (V){__builtin_fmaxf(pe.x, pm.x), __builtin_fmaxf(pe.y, pm.y)};   // NaN is made to propagate below
+                if constexpr (CHECK == CHECK_BLOCK) track(r - 1);
+                store_traj_row(r);
+            };
+            int i = 0;
+            while (i < n_run) {
+                seed((double)i * hd, Er, Ei, tg);
+                const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
+                for (; i + 2 <= end; i += 2) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    rk4_step(i + 1);
+                    save_row(i + 2);
+                }
+                if (i < end) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    ++i;
+                }
+            }
+            if (pe.x != pe.x) pm.x = pe.x;   // np.max over the saved rows propagates NaN (sticky in y)
+            if (pe.y != pe.y) pm.y = pe.y;
+            store_rows(A.a_end);
+            write_summary();
+            return;
+        }
+    }
 
     constexpr int CHUNK = RESYNC / 2;
     int i = 0, since_seed = RESYNC, row = 0;
@@ -161,14 +237,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     if constexpr (CHECK == CHECK_BLOCK) {
         if (n_run > 0) track(n_run - 1);
     }
-    A.p_end[pt[0]] = pe.x;
-    A.p_max[pt[0]] = pm.x;
-    A.first_bad[pt[0]] = bad[0];
-    if (live1) {
-        A.p_end[pt[1]] = pe.y;
-        A.p_max[pt[1]] = pm.y;
-        A.first_bad[pt[1]] = bad[1];
-    }
+    write_summary();
 }
 
 template <int NW, int CHECK, bool TRAJ>

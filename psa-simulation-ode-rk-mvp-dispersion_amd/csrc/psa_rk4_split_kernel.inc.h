@@ -148,12 +148,29 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     const int n_rows = A.n_steps / se;
     const int n_run = (CHECK != CHECK_NONE) ? A.n_steps : n_rows * se;
 
+    // trajectory rows [row][wave][N][2]: the lane writes its own waves' (re, im) pairs.  wave_of[j] = U_j + role * R_j, so the
+    // address splits into a wave-uniform part (row, U_j: an SGPR pair) and a per-lane constant 32-bit byte offset
+    // (role * R_j * N + idx) * 16 -- the global_store saddr form of rk4_sweep_kernel, no vector instruction spent on
+    // addressing inside the z-loop.  (The C-ABI keeps NW * N * 16 B < 2^32 for two-lane trajectory launches.)
     using Pair = typename PairOf<double>::type;
+    unsigned lane_off[NL];
+    int wave_u[NL];
+    if constexpr (NL == 2) {
+        wave_u[0] = 0;
+        wave_u[1] = 1;
+        lane_off[0] = lane_off[1] = (unsigned)((unsigned long long)(role * 2 * N + idx) * sizeof(Pair));
+    } else {
+        wave_u[0] = 0;
+        wave_u[1] = 2;
+        wave_u[2] = 3;
+        lane_off[0] = (unsigned)((unsigned long long)(role * N + idx) * sizeof(Pair));
+        lane_off[1] = lane_off[2] = (unsigned)((unsigned long long)(role * 2 * N + idx) * sizeof(Pair));
+    }
     auto store_traj_row = [&](const int r) {
-        Pair *dst = reinterpret_cast<Pair *>(A.traj) + (long long)r * NW * N + idx;
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            __builtin_nontemporal_store(Pair{y[2 * j], y[2 * j + 1]}, dst + (long long)wave_of[j] * N);
+            store_pair_nt(rowb + (long long)wave_u[j] * N * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
     };
     auto store_a_end = [&]() {
 #pragma unroll
@@ -183,6 +200,48 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
             if (bad < 0 && point_nonfinite()) bad = step_index;
         }
     };
+
+    // ---- save_every == 1 with a trajectory: every step is a saved row -- the dedicated loop of rk4_sweep_kernel (per row:
+    // |A_sig|^2, running maximum, block-mode finite test, the lane's NL streaming stores; two steps per trip).
+    if constexpr (TRAJ) {
+        if (se == 1) {
+            auto save_row = [&](const int r) {
+                pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
+                pm = pe > pm ? pe : pm;               // NaN is made to propagate after the loop (it is sticky in y)
+                if constexpr (CHECK == CHECK_BLOCK) {
+                    if (bad < 0 && point_nonfinite()) bad = r - 1;
+                }
+                store_traj_row(r);
+            };
+            int i = 0;
+            while (i < n_run) {
+                double c, s;
+                Phase<double>::eval(dbd * ((double)i * hd), c, s);
+                Er = e_amp * c;
+                Ei = e_amp * s;
+                const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
+                for (; i + 2 <= end; i += 2) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    rk4_step(i + 1);
+                    save_row(i + 2);
+                }
+                if (i < end) {
+                    rk4_step(i);
+                    save_row(i + 1);
+                    ++i;
+                }
+            }
+            if (pe != pe) pm = pe;
+            store_a_end();
+            if (owns_signal) {
+                A.p_end[idx] = pe;
+                A.p_max[idx] = pm;
+            }
+            if (role == 0) A.first_bad[idx] = bad;
+            return;
+        }
+    }
 
     constexpr int CHUNK = RESYNC / 2;
     int i = 0, since_seed = RESYNC, row = 0;

@@ -190,10 +190,36 @@ def test_dbeta_producer_validates_its_model_before_any_launch():
 
 
 def test_n_points_beyond_the_launch_grid_is_too_large():
+    """PSA_MAX_POINTS = 2^31 - 256: what a launch really takes (2^32 - 1 threads in x; the two-lane layout uses two per
+    point) -- checked before any allocation or launch, so an oversized sweep gets the documented code, not a raw
+    hipErrorInvalidConfiguration."""
     buf = np.zeros(64)
     p = buf.ctypes.data_as(C.c_void_p)
-    rc = nat.lib().psa_rk4_sweep_f64_dev(None, 4, 64 * (2**31 - 1) + 1, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, None)
-    assert rc == -9
+    L = nat.lib()
+    src = open(HEADER, encoding="utf-8").read()
+    assert int(re.search(r"#define\s+PSA_MAX_POINTS\s+(\d+)LL", src).group(1)) == nat.MAX_POINTS == 2**31 - 256
+    assert L.psa_rk4_sweep_f64_dev(None, 4, nat.MAX_POINTS + 1, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, None) == -9
+    assert L.psa_rk4_sweep_f32_dev(None, 4, 2**32, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, None) == -9
+    assert L.psa_rk4_sweep_f64(0, 4, nat.MAX_POINTS + 1, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, None, None) == -9
+
+
+def test_trajectory_launch_limits_and_contradictory_flags():
+    """Trajectory rows are addressed with a 32-bit lane offset kept below 2^31 (float64: < 2^27 points, float32: < 2^28; two
+    lanes per point: n_waves * N * 16 B < 2^32); SPLIT_POINT + ONE_LANE and F32_SCALAR + F32_PACKED are rejected."""
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    L = nat.lib()
+
+    def f64(n, flags=0, nw=4, traj=p):
+        return L.psa_rk4_sweep_f64_dev(None, nw, n, 10, 1.0, 1, p, p if nw == 6 else None, p, p, p, flags, p, p, p, p, traj)
+    assert f64(2**27) == -9 and b"trajectory" in L.psa_last_error()
+    assert L.psa_rk4_sweep_f32_dev(None, 4, 2**28, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, p) == -9
+    assert f64(2**26, nat.OPT_SPLIT_POINT) == -9 and f64(2**26 // 6 * 4 + 8, nat.OPT_SPLIT_POINT, nw=6) == -9
+    assert f64(8, nat.OPT_SPLIT_POINT | nat.OPT_ONE_LANE, traj=None) == -11
+    assert L.psa_rk4_sweep_f32_dev(None, 4, 8, 10, 1.0, 1, p, None, p, p, p, nat.OPT_F32_SCALAR | nat.OPT_F32_PACKED,
+                                   p, p, p, p, None) == -11
+    assert b"exclude" in L.psa_last_error()
+    assert L.psa_release_cache() >= 0
 
 
 def test_dbeta_model_description_of_the_python_carriers():

@@ -550,14 +550,14 @@ def test_trajectory_leaves_the_device_in_chunks(oracle):
 
 
 def test_a_trajectory_that_cannot_fit_is_refused_before_any_allocation():
-    """PSA_E_TOO_LARGE (-9), not hipErrorOutOfMemory: 2^27 points x 100 001 rows = 8.6e14 B.  The call returns from its
+    """PSA_E_TOO_LARGE (-9), not hipErrorOutOfMemory: 2^26 points x 100 001 rows = 4.3e14 B.  The call returns from its
     size check, so the small dummy buffers are never read or written."""
     import ctypes as C
     buf = np.zeros(64)
     p = buf.ctypes.data_as(C.c_void_p)
     L = nat.lib()
     flags = nat.BCAST_GAMMA | nat.BCAST_ALPHA | nat.BCAST_A0
-    rc = L.psa_rk4_sweep_f64(0, 4, 2**27, 100_000, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p, None)
+    rc = L.psa_rk4_sweep_f64(0, 4, 2**26, 100_000, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p, None)
     assert rc == -9 and b"does not fit" in L.psa_last_error()
     rc = L.psa_rk4_sweep_f64_dev(None, 4, 2**28, 10, 1.0, 1, p, None, p, p, p, flags, p, p, p, p, p)
     assert rc == -9                                                   # trajectory launches address lanes with 32 bits

@@ -38,8 +38,12 @@ template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_
 // Streaming store of one (re, im) pair at  sbase + voff : sbase wave-uniform (an SGPR pair), voff the lane's 32-bit byte
 // offset.  This is the global_store "saddr" form; written as inline assembly because the compiler, left to itself, widens
 // the lane offset to 64 bits inside the z-loop and then spends a v_lshl_add_u64 per store on the address.
+// HAZARD: on gfx90a / gfx940 / gfx950 a VMEM store of MORE than 64 bits of data must not be followed within two wait
+// states by a VALU instruction that overwrites the data VGPRs (LLVM's GCNHazardRecognizer inserts the s_nop for stores it
+// can see; it cannot see into inline assembly).  The 16-B forms therefore carry their own `s_nop 1`: without it the packed
+// float32 kernel, which assembles each store's four floats in a temporary it reuses at once, wrote corrupt rows.
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<double>::type v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<float>::type v) {
     asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
@@ -47,7 +51,7 @@ __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned 
 // two adjacent float32 points' (re, im) pairs in one 16-B store (the packed kernel: points 2i and 2i+1 share a lane)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_quad_nt(const void *sbase, const unsigned voff, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
 // cos/sin of a float64 phase, delivered in the working precision.

@@ -116,12 +116,14 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     const unsigned lane_off = (unsigned)idx * 16u;
     auto store_traj_row = [&](const int r) {
         const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * 8;
+        if (wave_full) {
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const char *wb = rowb + (long long)j * N * 8;
-            if (wave_full) {
-                store_quad_nt(wb, lane_off, (f32x4){y[2 * j].x, y[2 * j + 1].x, y[2 * j].y, y[2 * j + 1].y});
-            } else {
+            for (int j = 0; j < NW; ++j)
+                store_quad_nt(rowb + (long long)j * N * 8, lane_off, (f32x4){y[2 * j].x, y[2 * j + 1].x, y[2 * j].y, y[2 * j + 1].y});
+        } else {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const char *wb = rowb + (long long)j * N * 8;
                 store_pair_nt(wb, lane_off, (f32x2){y[2 * j].x, y[2 * j + 1].x});
                 if (live1) store_pair_nt(wb, lane_off + 8u, (f32x2){y[2 * j].y, y[2 * j + 1].y});
             }

@@ -5,7 +5,7 @@ PhaseMismatchCalculator :218-243), plus ``compute_phase_mismatch_batch`` which s
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from enum import Enum
 from typing import Optional, Sequence, Tuple
 
@@ -22,14 +22,57 @@ class PhaseMatchingMethod(str, Enum):
     PROVIDED = "provided"               # a constant supplied by the caller
 
 
-def _nonneg_real(x, name):
+@dataclass(frozen=True)
+class PhaseMatchingResult:
+    delta_beta: float
+    symmetric: Optional[SymmetricPlan] = None
+
+
+# ---- PhaseMatchingConfig: field rules as data ----------------------------------------------------------------------
+# Each rule takes the raw field value and returns what is stored (or raises); cross-field constraints follow.  The messages
+# are the reference's (tests/golden/error_contract.json pins type and text of what upstream raises, phase_matching.py:106-137).
+def _finite_real(name):
+    def rule(x):
+        try:
+            v = float(x)
+        except Exception as e:
+            raise TypeError(f"{name} must be a real scalar, got {type(x)!r}") from e
+        if not np.isfinite(v):
+            raise ValueError(f"{name} must be finite, got {v!r}")
+        return v
+    return rule
+
+
+def _method_rule(m):
+    if isinstance(m, PhaseMatchingMethod):
+        return m
     try:
-        v = float(x)
+        return PhaseMatchingMethod(str(m))
     except Exception as e:
-        raise TypeError(f"{name} must be a real scalar, got {type(x)!r}") from e
-    if not np.isfinite(v):
-        raise ValueError(f"{name} must be finite, got {v!r}")
-    return v
+        raise ValueError(f"Invalid method {m!r}") from e
+
+
+def _max_order_rule(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError(f"max_order must be int >= 0, got {n!r}")
+    return n
+
+
+def _even_orders_rule(orders):
+    seq = tuple(orders)
+    if not seq:
+        raise ValueError("even_orders must not be empty (e.g., (2,4))")
+    for n in seq:
+        if not isinstance(n, int):
+            raise TypeError("even_orders must contain ints")
+        if n < 2 or n % 2:
+            raise ValueError(f"even_orders must contain even ints >= 2, got {n!r}")
+    return orders          # stored as given
+
+
+_FIELD_RULES = (("method", _method_rule), ("max_order", _max_order_rule), ("even_orders", _even_orders_rule),
+                ("atol", _finite_real("atol")), ("rtol", _finite_real("rtol")))
+_PROVIDED_RULE = _finite_real("provided_delta_beta")
 
 
 @dataclass(frozen=True)
@@ -42,48 +85,24 @@ class PhaseMatchingConfig:
     provided_delta_beta: Optional[float] = None   # PROVIDED only
 
     def __post_init__(self) -> None:
-        if not isinstance(self.method, PhaseMatchingMethod):
-            try:
-                object.__setattr__(self, "method", PhaseMatchingMethod(str(self.method)))
-            except Exception as e:
-                raise ValueError(f"Invalid method {self.method!r}") from e
-        if not isinstance(self.max_order, int) or self.max_order < 0:
-            raise ValueError(f"max_order must be int >= 0, got {self.max_order!r}")
-        orders = tuple(self.even_orders)
-        if not orders:
-            raise ValueError("even_orders must not be empty (e.g., (2,4))")
-        for n in orders:
-            if not isinstance(n, int):
-                raise TypeError("even_orders must contain ints")
-            if n < 2 or n % 2:
-                raise ValueError(f"even_orders must contain even ints >= 2, got {n!r}")
-        a, r = _nonneg_real(self.atol, "atol"), _nonneg_real(self.rtol, "rtol")
-        if a < 0.0 or r < 0.0:
+        for name, rule in _FIELD_RULES:
+            object.__setattr__(self, name, rule(getattr(self, name)))
+        if min(self.atol, self.rtol) < 0.0:
             raise ValueError("atol and rtol must be >= 0")
-        object.__setattr__(self, "atol", a)
-        object.__setattr__(self, "rtol", r)
-        if self.method == PhaseMatchingMethod.PROVIDED:
+        if self.method is PhaseMatchingMethod.PROVIDED:
             if self.provided_delta_beta is None:
                 raise ValueError("provided_delta_beta must be set when method == 'provided'")
-            object.__setattr__(self, "provided_delta_beta",
-                               _nonneg_real(self.provided_delta_beta, "provided_delta_beta"))
+            object.__setattr__(self, "provided_delta_beta", _PROVIDED_RULE(self.provided_delta_beta))
 
     def scaled(self, length_scale: float) -> "PhaseMatchingConfig":
         """PROVIDED dbeta per (length unit / length_scale) -- simulation.py:153-175; other methods unchanged."""
         s = float(length_scale)
         if self.method != PhaseMatchingMethod.PROVIDED or s == 1.0:
             return self
-        return PhaseMatchingConfig(method=PhaseMatchingMethod.PROVIDED, max_order=self.max_order,
-                                   even_orders=self.even_orders, atol=self.atol, rtol=self.rtol,
-                                   provided_delta_beta=float(self.provided_delta_beta) / s)
+        return replace(self, provided_delta_beta=float(self.provided_delta_beta) / s)
 
 
-@dataclass(frozen=True)
-class PhaseMatchingResult:
-    delta_beta: float
-    symmetric: Optional[SymmetricPlan] = None
-
-
+# ---- one strategy per method, scalar (one plan, raises) and batched (a sweep, masks) ---------------------------------
 def _omega4(omegas, name="omegas") -> np.ndarray:
     arr = np.asarray(list(omegas), dtype=float)
     if arr.shape != (4,):
@@ -95,25 +114,58 @@ def _omega4(omegas, name="omegas") -> np.ndarray:
     return arr
 
 
+def _one_provided(om, disp, cfg, hint):
+    return PhaseMatchingResult(float(cfg.provided_delta_beta), None)
+
+
+def _one_taylor(om, disp, cfg, hint):
+    db = delta_beta_from_omegas(om, disp, max_order=cfg.max_order, atol=cfg.atol, rtol=cfg.rtol)
+    return PhaseMatchingResult(float(db), None)
+
+
+def _one_symmetric(om, disp, cfg, hint):
+    sp = hint if hint is not None else infer_symmetry_from_omegas(*(float(w) for w in om), atol=cfg.atol, rtol=cfg.rtol)
+    return PhaseMatchingResult(float(delta_beta_symmetric(sp.omega_c, sp.omega_d, sp.Omega, disp,
+                                                          even_orders=cfg.even_orders)), sp)
+
+
+def _many_provided(om, disp, cfg):
+    return np.full(om.shape[0], float(cfg.provided_delta_beta)), True
+
+
+def _many_taylor(om, disp, cfg):
+    ok = _conserves(om[:, 0] + om[:, 1], om[:, 2] + om[:, 3], cfg.atol, cfg.rtol)
+    return delta_beta_from_omegas_array(om, disp, max_order=cfg.max_order), ok
+
+
+def _many_symmetric(om, disp, cfg):
+    _, od, Om, ok = symmetry_arrays(om[:, 0], om[:, 1], om[:, 2], om[:, 3], atol=cfg.atol, rtol=cfg.rtol)
+    return delta_beta_symmetric_array(od, Om, disp, even_orders=cfg.even_orders), ok
+
+
+# method -> (scalar strategy, batched strategy, needs a dispersion model)
+_STRATEGIES = {
+    PhaseMatchingMethod.PROVIDED: (_one_provided, _many_provided, False),
+    PhaseMatchingMethod.GENERAL_TAYLOR: (_one_taylor, _many_taylor, True),
+    PhaseMatchingMethod.SYMMETRIC_EVEN: (_one_symmetric, _many_symmetric, True),
+}
+
+
+def _strategy(cfg, disp):
+    try:
+        one, many, needs_disp = _STRATEGIES[cfg.method]
+    except KeyError:
+        raise ValueError(f"Unsupported phase-matching method: {cfg.method!r}") from None
+    if needs_disp and disp is None:
+        raise ValueError("disp must be provided unless method == 'provided'")
+    return one, many
+
+
 def compute_phase_mismatch(omegas: Sequence[float], disp: Optional[DispersionParams], cfg: PhaseMatchingConfig, *,
                            symmetric_hint: Optional[SymmetricPlan] = None) -> PhaseMatchingResult:
     """dbeta for one plan [w1, w2, w3, w4]; raises like the reference (phase_matching.py:177-215)."""
     om = _omega4(omegas)
-    if cfg.method == PhaseMatchingMethod.PROVIDED:
-        return PhaseMatchingResult(float(cfg.provided_delta_beta), None)
-    if disp is None:
-        raise ValueError("disp must be provided unless method == 'provided'")
-    if cfg.method == PhaseMatchingMethod.GENERAL_TAYLOR:
-        return PhaseMatchingResult(float(delta_beta_from_omegas(om, disp, max_order=cfg.max_order, atol=cfg.atol,
-                                                                rtol=cfg.rtol)), None)
-    if cfg.method == PhaseMatchingMethod.SYMMETRIC_EVEN:
-        sp = symmetric_hint
-        if sp is None:
-            sp = infer_symmetry_from_omegas(float(om[0]), float(om[1]), float(om[2]), float(om[3]),
-                                            atol=cfg.atol, rtol=cfg.rtol)
-        return PhaseMatchingResult(float(delta_beta_symmetric(sp.omega_c, sp.omega_d, sp.Omega, disp,
-                                                              even_orders=cfg.even_orders)), sp)
-    raise ValueError(f"Unsupported phase-matching method: {cfg.method!r}")
+    return _strategy(cfg, disp)[0](om, disp, cfg, symmetric_hint)
 
 
 def compute_phase_mismatch_batch(omega: np.ndarray, disp: Optional[DispersionParams], cfg: PhaseMatchingConfig
@@ -127,22 +179,10 @@ def compute_phase_mismatch_batch(omega: np.ndarray, disp: Optional[DispersionPar
     om = np.asarray(omega, dtype=float)
     if om.ndim != 2 or om.shape[1] != 4:
         raise ValueError(f"omega must have shape (N, 4), got {om.shape}")
+    many = _strategy(cfg, disp)[1]
     with np.errstate(all="ignore"):
-        ok = np.all(np.isfinite(om), axis=1) & np.all(om > 0.0, axis=1)
-        if cfg.method == PhaseMatchingMethod.PROVIDED:
-            db = np.full(om.shape[0], float(cfg.provided_delta_beta))
-        else:
-            if disp is None:
-                raise ValueError("disp must be provided unless method == 'provided'")
-            if cfg.method == PhaseMatchingMethod.GENERAL_TAYLOR:
-                ok &= _conserves(om[:, 0] + om[:, 1], om[:, 2] + om[:, 3], cfg.atol, cfg.rtol)
-                db = delta_beta_from_omegas_array(om, disp, max_order=cfg.max_order)
-            else:
-                _, od, Om, sym_ok = symmetry_arrays(om[:, 0], om[:, 1], om[:, 2], om[:, 3], atol=cfg.atol,
-                                                    rtol=cfg.rtol)
-                ok &= sym_ok
-                db = delta_beta_symmetric_array(od, Om, disp, even_orders=cfg.even_orders)
-        ok &= np.isfinite(db)
+        db, ok_method = many(om, disp, cfg)
+        ok = np.all(np.isfinite(om), axis=1) & np.all(om > 0.0, axis=1) & ok_method & np.isfinite(db)
         db = np.where(ok, db, np.nan)
     return db, ok
 

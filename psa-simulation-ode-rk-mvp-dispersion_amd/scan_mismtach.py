@@ -230,6 +230,8 @@ def _sweep_gain(*, cfg, lam1, grid_axes, gamma, alpha, p0, ph0, dispersion, pm_c
     from the UNSCALED dispersion like scan_mismtach.py:700-706) block by block.  Returns (gain[N], dbeta_caller[N] | None,
     SweepResult | None).  Never raises for per-point or cfg problems: those become NaN, as ``except Exception`` does upstream.
     """
+    if dbeta_producer not in ("auto", "host", "device"):       # a caller error, not a per-point failure
+        raise ValueError("dbeta_producer must be 'auto', 'host' or 'device'")
     ax2, ax3 = np.atleast_1d(grid_axes[0]), np.atleast_1d(grid_axes[1])
     N = ax2.size * ax3.size
     shard = _Shard(N, device)

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -284,6 +285,15 @@ struct Carver {
 // staging for the trajectory transpose of the host-buffer API: two buffers of at most this many bytes each
 constexpr size_t TRAJ_STAGE_BYTES = 256u << 20;
 
+#ifdef PSA_FAULT_INJECTION
+// Sanitizer builds only (tools/host_sanitize.sh): PSA_FAIL_CHUNK=k makes the k-th staged trajectory chunk of every call
+// fail, so the error path OUT of the staging loop (streams drained, per-call buffers freed, context returned) runs under ASan.
+static bool injected_chunk_failure(size_t chunk_index) {
+    const char *e = getenv("PSA_FAIL_CHUNK");
+    return e && (size_t)atoll(e) == chunk_index;
+}
+#endif
+
 #define HIP_RET(expr)                                                \
     do {                                                             \
         hipError_t _e = (expr);                                      \
@@ -439,6 +449,9 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
         int b = 0;
         for (size_t p0 = 0; p0 < N; p0 += chunk_pts, b ^= 1) {
             const size_t pts = (N - p0 < chunk_pts) ? N - p0 : chunk_pts;
+#ifdef PSA_FAULT_INJECTION
+            if (injected_chunk_failure(p0 / chunk_pts)) return hip_fail(hipErrorUnknown, "injected failure in the staging loop");
+#endif
             // stream order on st_copy[b] keeps the staging buffer busy until its previous copy has finished
             HIP_RET(Launch<T>::t2a(cx.st_copy[b], d_traj + 2 * p0, d_stage[b], (long long)pts, (long long)N,
                                    (long long)n_saved, nc));

@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/hbm_write_peak.hip -o tools/hbm_write_peak ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -28,9 +29,10 @@ __global__ void __launch_bounds__(256) rows_kernel(d2 *traj, long long n, int ro
     }
 }
 
-int main() {
-    const long long n = 262144;
-    const int rows = 401;
+int main(int argc, char **argv) {   // [points = 262144] [rows = 401]: the two-lane trajectory shape is 32768 x 3201
+    const long long n = argc > 1 ? atoll(argv[1]) : 262144;
+    const int rows = argc > 2 ? atoi(argv[2]) : 401;
+    printf("-- store-only ceiling, %lld points x %d rows x 4 waves x 16 B\n", n, rows);
     d2 *buf;
     const size_t bytes = (size_t)rows * 4 * n * sizeof(d2);
     if (hipMalloc(&buf, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -42,8 +44,8 @@ int main() {
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipEventRecord(e0);
-                if (nt) hipLaunchKernelGGL(rows_kernel<true>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
-                else hipLaunchKernelGGL(rows_kernel<false>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                if (nt) hipLaunchKernelGGL(rows_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                else hipLaunchKernelGGL(rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf, n, rows, spin);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
@@ -53,8 +55,8 @@ int main() {
             // the same launch 100 times back to back, no host synchronisation in between (sustained rate)
             hipEventRecord(e0);
             for (int rep = 0; rep < 100; ++rep) {
-                if (nt) hipLaunchKernelGGL(rows_kernel<true>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
-                else hipLaunchKernelGGL(rows_kernel<false>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                if (nt) hipLaunchKernelGGL(rows_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf, n, rows, spin);
+                else hipLaunchKernelGGL(rows_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, buf, n, rows, spin);
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);

@@ -18,9 +18,12 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_Z = {"c2": 100_000, "c3": 100_000, "c4": 1_000_000, "c5": 100_000, "c5one": 100_000, "traj": 400}
-LANES_PER_POINT = {"c2": 1.0, "c3": 1.0, "c4": 0.5, "c5": 2.0, "c5one": 1.0, "traj": 1.0}
-KEY = {"traj": "trajectory"}
+N_Z = {"c2": 100_000, "c2x": 100_000, "c3": 100_000, "c4": 1_000_000, "c5": 100_000, "c5one": 100_000, "traj": 400,
+       "trajf32": 400, "traj6": 400, "traj4s": 3200, "traj6s": 2000}
+LANES_PER_POINT = {"c2": 1.0, "c2x": 1.0, "c3": 1.0, "c4": 0.5, "c5": 2.0, "c5one": 1.0, "traj": 1.0, "trajf32": 0.5, "traj6": 1.0,
+                   "traj4s": 2.0, "traj6s": 2.0}
+KEY = {"traj": "trajectory", "trajf32": "traj_c4", "traj6": "traj_c5", "traj4s": "traj_c2split", "traj6s": "traj_c5split",
+       "c2x": "c2_exact_step"}
 
 
 def one(pattern):
@@ -80,11 +83,11 @@ def main(src, tag):
         kernel = dom["Name"]
         rec = {"kernel": kernel, "calls": int(dom["Calls"]), "avg_ms": float(dom["AverageNs"]) / 1e6,
                "min_ms": float(dom["MinNs"]) / 1e6, "lanes_per_point": LANES_PER_POINT[cfg],
-               "source": f"rocprofv3 --kernel-trace --stats / --pmc passes of tools/profile_r02.sh ({tag}), "
+               "source": f"rocprofv3 --kernel-trace --stats / --pmc passes of tools/profile_{tag}.sh ({tag}), "
                          f"profiles/{tag}_{cfg}_kernel_stats.csv + profiles/{tag}_{cfg}_pmc.csv"}
         counters = {}
         durations = {}
-        for grp in ("sq", "grbm", "fetch", "write"):
+        for grp in ("sq", "grbm", "fetch", "write", "flops"):
             cc = one(os.path.join(src, f"{cfg}_pmc_{grp}", "**", "*_counter_collection.csv"))
             cdb = one(os.path.join(src, f"{cfg}_pmc_{grp}", "**", "*_results.db"))
             if cc:
@@ -109,6 +112,26 @@ def main(src, tag):
             if "SQ_INSTS_VALU" in med and med.get("SQ_WAVES"):
                 rec["valu_insts_per_wave_step"] = med["SQ_INSTS_VALU"] / med["SQ_WAVES"] / N_Z[cfg]
                 rec["waves"] = med["SQ_WAVES"]
+            # executed floating-point work: wave-instruction counts of the FMA / MUL / ADD classes (an FMA = 2 flops per lane;
+            # a packed float32 instruction does two per lane and is counted by SQ_INSTS_VALU_FLOPS_FP32 accordingly), per lane
+            # per z-step.  The dedicated gfx950 counter SQ_INSTS_VALU_FLOPS_FP64/32 is kept beside the sum as a cross-check.
+            for suf in ("F64", "F32"):
+                fma, mul, add = (med.get(f"SQ_INSTS_VALU_{k}_{suf}") for k in ("FMA", "MUL", "ADD"))
+                if fma is None or not med.get("SQ_WAVES") and not rec.get("waves"):
+                    continue
+                if suf == "F32" and cfg not in ("c4", "trajf32"):
+                    continue
+                if suf == "F64" and cfg in ("c4", "trajf32"):
+                    continue
+                waves = rec.get("waves") or med.get("SQ_WAVES")
+                per_wave_step = (2 * fma + (mul or 0) + (add or 0)) / waves / N_Z[cfg]
+                pack = 2.0 if suf == "F32" else 1.0          # v_pk_* : one wave-instruction = two lanes' worth per lane
+                rec["executed_flops_per_lane_step"] = per_wave_step * pack
+                rec["executed_flops_counters"] = {k: med[k] for k in med if k.startswith("SQ_INSTS_VALU_") and
+                                                  k.split("_")[-1] in ("F64", "F32", "FP64", "FP32", "CVT")}
+                flc = med.get("SQ_INSTS_VALU_FLOPS_FP64" if suf == "F64" else "SQ_INSTS_VALU_FLOPS_FP32")
+                if flc:
+                    rec["flops_counter_per_wave_step"] = flc / waves / N_Z[cfg]
             if "GRBM_GUI_ACTIVE" in med and "grbm" in durations:
                 dur = statistics.median(list(durations["grbm"].values()))
                 rec["held_clock_ghz"] = med["GRBM_GUI_ACTIVE"] / 8 / (dur * 1e-3) / 1e9

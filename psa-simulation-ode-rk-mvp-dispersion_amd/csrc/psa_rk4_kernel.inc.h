@@ -42,8 +42,11 @@ template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_
 // states by a VALU instruction that overwrites the data VGPRs (LLVM's GCNHazardRecognizer inserts the s_nop for stores it
 // can see; it cannot see into inline assembly).  The 16-B forms therefore carry their own `s_nop 1`: without it the packed
 // float32 kernel, which assembles each store's four floats in a temporary it reuses at once, wrote corrupt rows.
+#ifndef PSA_TRAJ_F64_MOD      // A/B hook (tools/ab_build.sh): -DPSA_TRAJ_F64_MOD='""' = default (write-back) stores
+#define PSA_TRAJ_F64_MOD " nt"
+#endif
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<double>::type v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" PSA_TRAJ_F64_MOD "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<float>::type v) {
     asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");

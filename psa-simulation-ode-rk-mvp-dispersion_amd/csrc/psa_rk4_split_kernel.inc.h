@@ -201,6 +201,38 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
         }
     };
 
+#ifdef PSA_SPLIT_TRAJ_SPREAD
+    // A/B hook (tools/ab_traj_stores.sh, profiles/r03_split_traj_ab.log): the same step, with the stores of the PREVIOUS row
+    // (y is unchanged until the step's last line) issued one per stage instead of as a burst after the step.  Measured
+    // SLOWER (32 768 points, every step saved: 1.71 vs 1.62 ms for 4 waves, 1.62 vs 1.54 for 6), as were default instead of
+    // non-temporal stores (1.64 / 1.56): with one wave per SIMD a store that finds the queue full stalls the only wave,
+    // wherever in the step it is issued.  Not compiled in.
+    auto store_traj_wave = [&](const int r, const int j) {
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
+        store_pair_nt(rowb + (long long)wave_u[j] * N * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
+    };
+    auto rk4_step_spread = [&](const int step_index, const int r_prev) {
+        double Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
+        split_stage<NL, LOSS>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);
+        store_traj_wave(r_prev, 0);
+        rotate(Er, Ei, rc, rs);
+        split_stage<NL, LOSS>(Y2, y, Er, Ei, g_d, tg_d, ha_d, Y3);
+        store_traj_wave(r_prev, 1);
+        const double E2r = Er + Er, E2i = Ei + Ei;
+        split_stage<NL, LOSS>(Y3, y, E2r, E2i, g_h, tg_h, ha_h, Y4);
+        if constexpr (NL == 3) store_traj_wave(r_prev, 2);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t[c] = fma_(2.0, Y3[c], fma_(-4.0, y[c], Y2[c])) + Y4[c];
+        rotate(Er, Ei, rc, rs);
+        split_stage<NL, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
+        if constexpr (CHECK == CHECK_EXACT) {
+            if (bad < 0 && point_nonfinite()) bad = step_index;
+        }
+    };
+#endif
+
     // ---- save_every == 1 with a trajectory: every step is a saved row -- the dedicated loop of rk4_sweep_kernel (per row:
     // |A_sig|^2, running maximum, block-mode finite test, the lane's NL streaming stores; two steps per trip).
     if constexpr (TRAJ) {
@@ -220,6 +252,16 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
                 Er = e_amp * c;
                 Ei = e_amp * s;
                 const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
+#ifdef PSA_SPLIT_TRAJ_SPREAD
+                for (; i < end; ++i) {      // row i was "saved" (summary only) after step i-1; its stores ride in step i
+                    if (i == 0) rk4_step(0); else rk4_step_spread(i, i);
+                    pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
+                    pm = pe > pm ? pe : pm;
+                    if constexpr (CHECK == CHECK_BLOCK) {
+                        if (bad < 0 && point_nonfinite()) bad = i;
+                    }
+                }
+#else
                 for (; i + 2 <= end; i += 2) {
                     rk4_step(i);
                     save_row(i + 1);
@@ -231,7 +273,11 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
                     save_row(i + 1);
                     ++i;
                 }
+#endif
             }
+#ifdef PSA_SPLIT_TRAJ_SPREAD
+            if (n_run > 0) store_traj_row(n_run);
+#endif
             if (pe != pe) pm = pe;
             store_a_end();
             if (owns_signal) {

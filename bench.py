@@ -316,7 +316,12 @@ def main() -> None:
                     help="summary (default): the BASELINE workload.  trajectory: the path's HBM-bound regime -- every "
                          "step saved (save_every = 1), 262 144 points x 400 z-steps, 6.7 GB of rows per launch; reports "
                          "an HBM roofline object.  Not the headline metric.")
-    ap.add_argument("--exact-step", action="store_true", help="per-step finite test instead of per save block")
+    ap.add_argument("--exact-step", action="store_true",
+                    help="the reference's per-step finite test (integrators.py:132-135).  Default for the float64 workloads, "
+                         "where the exact first_bad_step costs nothing in the loop (block test + replay of a failing block); "
+                         "for float32 (c4) this flag turns on the packed kernel's in-loop test")
+    ap.add_argument("--block-check", action="store_true", help="float64: test once per saved row only (first_bad_step = the "
+                                                                "last step of the first non-finite block)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 100 if args.mode == "trajectory" else 10
@@ -374,7 +379,8 @@ def main() -> None:
 
     # -- synthetic inputs of the workload, resident in HBM (rank's contiguous block of the global sweep)
     flags = (nat.OPT_BLOCK64 if args.block64 else 0) | (nat.OPT_ONE_LANE if args.one_lane else 0)
-    sweep, n_global, host_dbeta = build_shard(args.config, world, rank, dev, extra_flags=flags, exact_step=args.exact_step)
+    exact = args.exact_step or (cfg["dtype"] == "f64" and not args.block_check)
+    sweep, n_global, host_dbeta = build_shard(args.config, world, rank, dev, extra_flags=flags, exact_step=exact)
     p0_sig = float(cfg["p_in"][2])
 
     def one_step(evs=None):
@@ -488,6 +494,8 @@ def main() -> None:
             "config": {"workload": f"BASELINE {cfg['baseline']}: {cfg['what']}", "name": args.config,
                        "sweep_pts_per_gpu": pts, "sweep_pts_total": n_global, "n_fields": nw, "n_zsteps": n_z,
                        "save_every": SAVE_EVERY, "check_nan": True,
+                       "first_bad_step": "exact (per-step test semantics of integrators.py:132-135)" if exact else
+                                         "last step of the first non-finite save block",
                        "parallelism": (f"sweep sharded x{world}, one RCCL all_gather per pass" if backend == "nccl" else
                                        f"REHEARSAL: {world} ranks over {n_dev} GPU(s), {backend} gather staged through the host")
                        if world > 1 else "single GPU"},

@@ -66,10 +66,13 @@ extern "C" {
 #define PSA_OPT_CHECK_NAN    (1u << 8)   /* SimulationConfig.check_nan (config.py:29): track first_bad_step over ALL
                                             n_steps (also the tail after the last saved row).  Without it
                                             first_bad_step is -1 everywhere and NaNs propagate silently.         */
-#define PSA_OPT_EXACT_STEP   (1u << 9)   /* with CHECK_NAN: test finiteness after EVERY step (exact index, as
-                                            integrators.py:132).  Without it the test runs once per save block and
-                                            first_bad_step is the LAST step of the first non-finite block (the
-                                            sweep drivers only need "did it fail").                              */
+#define PSA_OPT_EXACT_STEP   (1u << 9)   /* with CHECK_NAN: first_bad_step is the EXACT step index, as the reference's
+                                            per-step test reports it (integrators.py:132-135).  float64: free -- the
+                                            forward pass tests once per saved row and a wave with a newly failing point
+                                            replays the steps since the previous test with a per-step test; float32:
+                                            tested in the loop.  Without the flag first_bad_step is the LAST step of
+                                            the first non-finite save block (the sweep drivers only need "did it
+                                            fail").                                                                */
 #define PSA_OPT_LDS_STAGING  (1u << 10)  /* keep y / y_stage / k-accumulator in LDS instead of VGPRs (the layout
                                             the north-star sketches; slower -- kept for the A/B in DESIGN.md)    */
 #define PSA_OPT_BLOCK64      (1u << 11)  /* 64-thread workgroups (one wave) instead of 256                       */

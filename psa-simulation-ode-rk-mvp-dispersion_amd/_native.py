@@ -173,9 +173,12 @@ def _prep(x, dtype, n_points: int, name: str):
 
 
 def sweep_host(dbeta, *, n_steps: int, z_max: float, save_every: int, gamma, alpha, a0, dbeta2=None,
-               check_nan: bool = True, exact_step: bool = False, want_traj: bool = False, dtype=np.float64,
+               check_nan: bool = True, exact_step: Optional[bool] = None, want_traj: bool = False, dtype=np.float64,
                device: int = 0, extra_flags: int = 0) -> dict:
     """Run N independent RK4 propagations on the GPU (host buffers in, host buffers out).
+
+    exact_step: None = exact first_bad_step in float64 (free there: block test + replay of a failing block) and the
+    per-save-block index in float32; True / False force either.
 
     dbeta (N,); gamma/alpha scalar or (N,); a0 (n_waves,) or (N, n_waves) complex.
     Returns a_end (N, n_waves) complex, p_end, p_max (N,), first_bad_step (N,) int64,
@@ -208,7 +211,7 @@ def sweep_host(dbeta, *, n_steps: int, z_max: float, save_every: int, gamma, alp
         flags |= BCAST_ALPHA
     if check_nan:
         flags |= OPT_CHECK_NAN
-        if exact_step:
+        if exact_step or (exact_step is None and dtype == np.float64):
             flags |= OPT_EXACT_STEP
     d2 = None
     if nw == 6:

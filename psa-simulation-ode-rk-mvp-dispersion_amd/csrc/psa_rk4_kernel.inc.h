@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     // which is the reference's k1..k4 combination regrouped (no change of variables, same truncation error; the
     // regrouping costs ~1 ulp(y) of rounding noise per step, ~1e-13 after 1e5 steps).  (Ed_r, Ed_i) carries
     // 2*d*gamma*exp(i*dbeta*z): on entry at z_step, on exit rotated to z_step + h.
-    auto rk4_step_reg = [&](const int step_index) {
+    auto rk4_step_on = [&](T (&y)[NC], T (&Er)[NP], T (&Ei)[NP]) {
         T Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
         yaman_stage<T, NW, true, LOSS>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);  // Y2 = y + d k1
 #pragma unroll
@@ -306,10 +306,10 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
         yaman_stage<T, NW, true, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);  // D = t + d k4
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
-        if constexpr (CHECK == CHECK_EXACT) {  // integrators.py:132-135, every step (a select, not a branch)
-            if (bad < 0 && any_nonfinite<T, NC>(y)) bad = step_index;
-        }
     };
+    // The per-step finite test of the reference (integrators.py:132-135) is NOT in the float64 step: CHECK_EXACT finds the
+    // exact index by REPLAY (below) -- the forward pass tests once per saved row, like CHECK_BLOCK.
+    auto rk4_step_reg = [&](const int) { rk4_step_on(y, Er, Ei); };
 
     // ---- float32: the classic low-storage form (y, y_stage, accumulator; 320 instructions).  The regrouping above
     // quantises every stage increment to ulp(y); harmless at 1e-16 but measured 17x worse at float32 (6.7e-3 vs
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
         A.p_max[idx] = pm;
         A.first_bad[idx] = bad;
     };
-    auto seed_phase = [&](const int step) {   // exact re-seed of the phase recurrence at z = step * h (wave-uniform)
+    auto seed_phase_on = [&](const int step, T (&Er)[NP], T (&Ei)[NP]) {   // exact re-seed of the phase recurrence at z = step * h
         const double z = (double)step * hd;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -373,6 +373,62 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
             Phase<T>::eval(dbd[p] * z, c, s);
             Er[p] = e_amp * c;
             Ei[p] = e_amp * s;
+        }
+    };
+    auto seed_phase = [&](const int step) { seed_phase_on(step, Er, Ei); };
+
+    // ---- CHECK_EXACT for the float64 register variant: exact first_bad_step at the price of the block test.  The state at
+    // the last test point (y, the carried phase factor, the steps since its seed) is kept; when a test finds a lane of the
+    // wave newly non-finite, the steps since then are REPLAYED on a copy with the reference's per-step test
+    // (integrators.py:132-135).  The replay repeats the forward pass operation for operation (same chunks, same re-seeds,
+    // same FMA sequence), so it reproduces this kernel's own trajectory bit for bit and the index it finds is exact.  Only
+    // waves with a failing lane ever take the (wave-uniform) branch: +20 VGPRs, no instruction in the steady-state loop
+    // (the per-step test cost 9.9 of 310.6 instructions per step, profiles/r03_c2x_pmc.csv).
+    constexpr bool REPLAY = FUSE && CHECK == CHECK_EXACT;
+    T y_chk[REPLAY ? NC : 1], Er_chk[REPLAY ? NP : 1], Ei_chk[REPLAY ? NP : 1];
+    int i_chk = 0, ss_chk = RESYNC;
+    auto checkpoint = [&](const int step, const int since_seed) {
+        if constexpr (REPLAY) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) y_chk[c] = y[c];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                Er_chk[p] = Er[p];
+                Ei_chk[p] = Ei[p];
+            }
+            i_chk = step;
+            ss_chk = since_seed;
+        }
+    };
+    auto exact_test = [&](const int i_now, const int since_seed) {   // at a test point: y is the state after step i_now - 1
+        if constexpr (REPLAY) {
+            const bool newly_bad = bad < 0 && any_nonfinite<T, NC>(y);
+            if (__builtin_amdgcn_ballot_w64(newly_bad) != 0) {
+                T yy[NC], er[NP], ei[NP];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) yy[c] = y_chk[c];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    er[p] = Er_chk[p];
+                    ei[p] = Ei_chk[p];
+                }
+                int ii = i_chk, ss = ss_chk;
+                while (ii < i_now) {
+                    if (ss >= RESYNC) {
+                        seed_phase_on(ii, er, ei);
+                        ss = 0;
+                    }
+                    const int e = (i_now - ii > RESYNC / 2) ? ii + RESYNC / 2 : i_now;
+#pragma nounroll
+                    for (int st = ii; st < e; ++st) {
+                        rk4_step_on(yy, er, ei);
+                        if (bad < 0 && any_nonfinite<T, NC>(yy)) bad = st;
+                    }
+                    ss += e - ii;
+                    ii = e;
+                }
+            }
+            checkpoint(i_now, since_seed);
         }
     };
 
@@ -385,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
             auto save_row = [&](const int r) {
                 pe = fma_(y[4], y[4], y[5] * y[5]);
                 pm = pe > pm ? pe : pm;               // NaN is made to propagate after the loop (it is sticky in y)
-                if constexpr (CHECK == CHECK_BLOCK) {
+                if constexpr (CHECK == CHECK_BLOCK || (CHECK == CHECK_EXACT && FUSE)) {   // a row is a step here: exact either way
                     if (bad < 0 && any_nonfinite<T, NC>(y)) bad = r - 1;
                 }
                 store_traj_row(r);
@@ -421,6 +477,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     int i = 0;
     int since_seed = RESYNC;           // forces the seed at i = 0
     int row = 0;
+    checkpoint(0, since_seed);
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
     while (i < n_run) {
         if (since_seed >= RESYNC) {    // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
@@ -449,6 +506,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
             if constexpr (CHECK == CHECK_BLOCK) {
                 if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i - 1;
             }
+            exact_test(i, since_seed);
             if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {  // A[-1]: the last saved row, not necessarily z_max (R8)
 #pragma unroll
@@ -462,6 +520,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     if constexpr (CHECK == CHECK_BLOCK) {  // covers the unsaved tail
         if (bad < 0 && n_run > 0 && any_nonfinite<T, NC>(y)) bad = n_run - 1;
     }
+    if (n_run > i_chk) exact_test(n_run, since_seed);   // the unsaved tail (REPLAY only; compiled out otherwise)
     write_summary();
 }
 

@@ -73,9 +73,27 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
 #pragma unroll
     for (int p = 0; p < NP; ++p) { Er[p] = tg; Ei[p] = V{}; }
 
-    V y_lo[NC];  // Kahan residue of the state
+    // Compensated state.  float32 loses the part of each increment (~1e-5 |y| at 1e6 steps) below ulp(y): plain y += inc
+    // drifts ~n * ulp (5e-3 at BASELINE config 4's 1e6 steps).  The state is therefore kept as  yb + dl : a base yb and a
+    // SMALL running offset dl that collects the increments (rounded at ulp(dl) ~ 1e-4 ulp(y)); y = fl(yb + dl) is formed once
+    // per step for the stage inputs, and every FOLD steps dl is folded into yb with its rounding residue kept (Fast2Sum).
+    // 16 + 8 + 24/FOLD instructions per step and component pair against 40 for a Kahan update of y every step.
+    constexpr int FOLD = 16;
+    V yb[NC], dl[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) y_lo[c] = V{};
+    for (int c = 0; c < NC; ++c) {
+        yb[c] = y[c];
+        dl[c] = V{};
+    }
+    auto fold = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const V sum = yb[c] + dl[c];
+            dl[c] = dl[c] - (sum - yb[c]);
+            yb[c] = sum;
+            y[c] = sum;
+        }
+    };
     V pe = fma_(y[4], y[4], y[5] * y[5]);
     V pm = pe;
     long long bad[2] = {-1, -1};
@@ -148,14 +166,10 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
 #pragma unroll
         for (int p = 0; p < NP; ++p) rotate(Er[p], Ei[p], rc[p], rs[p]);
         yaman_rhs<V, NW>(ys, Er, Ei, g, tg, ha, k);
-        // compensated state update: the increment (~1e-5 |y| at 1e6 steps) is added with its rounding residue kept
-        // in y_lo, otherwise float32 loses it at ulp(y) per step and the error grows ~n (5e-3 at 1e6 steps).
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const V inc = fma_(h6, acc[c] + k[c], y_lo[c]);  // increment + carried residue
-            const V sum = y[c] + inc;
-            y_lo[c] = inc - (sum - y[c]);
-            y[c] = sum;
+            dl[c] = fma_(h6, acc[c] + k[c], dl[c]);   // the increment joins the small offset ...
+            y[c] = yb[c] + dl[c];                     // ... and y is the rounded state again (next stage input, saved rows)
         }
         if constexpr (CHECK == CHECK_EXACT) track(step_index);
     };
@@ -181,6 +195,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
             int i = 0;
             while (i < n_run) {
                 seed((double)i * hd, Er, Ei, tg);
+                fold();                               // RESYNC == FOLD steps since the last one
                 const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
                 for (; i + 2 <= end; i += 2) {
                     rk4_step(i);
@@ -203,12 +218,16 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     }
 
     constexpr int CHUNK = RESYNC / 2;
-    int i = 0, since_seed = RESYNC, row = 0;
+    int i = 0, since_seed = RESYNC, row = 0, since_fold = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
     while (i < n_run) {
         if (since_seed >= RESYNC) {
             seed((double)i * hd, Er, Ei, tg);
             since_seed = 0;
+        }
+        if (since_fold >= FOLD) {
+            fold();
+            since_fold = 0;
         }
         int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
         end = end < next_save ? end : next_save;
@@ -221,6 +240,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
         if (j < m) rk4_step(i + j);
         i = end;
         since_seed += m;
+        since_fold += m;
         if (i == next_save) {
             ++row;
             pe = fma_(y[4], y[4], y[5] * y[5]);

@@ -136,13 +136,14 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     double pm = pe;
     long long bad = -1;
     // any component of the POINT non-finite (own lane's or the partner's)
-    auto point_nonfinite = [&]() -> bool {
+    auto nonfinite_on = [&](const double (&v)[NC]) -> bool {
         double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) t = fma_(y[c], 0.0, t);
+        for (int c = 0; c < NC; ++c) t = fma_(v[c], 0.0, t);
         t += from_partner(t);
         return t != t;
     };
+    auto point_nonfinite = [&]() -> bool { return nonfinite_on(y); };
 
     const int se = A.save_every;
     const int n_rows = A.n_steps / se;
@@ -182,8 +183,9 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) store_a_end();
 
-    // one RK4 step, regrouped exactly as rk4_step_reg of rk4_sweep_kernel (integrators.py:54-59)
-    auto rk4_step = [&](const int step_index) {
+    // one RK4 step, regrouped exactly as rk4_step_on of rk4_sweep_kernel (integrators.py:54-59); the per-step finite test of
+    // CHECK_EXACT is not in it: the exact index comes from a replay (exact_test below), as in rk4_sweep_kernel
+    auto rk4_step_on = [&](double (&y)[NC], double &Er, double &Ei) {
         double Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];
         split_stage<NL, LOSS>(y, y, Er, Ei, g_d, tg_d, ha_d, Y2);
         rotate(Er, Ei, rc, rs);  // z + h/2
@@ -196,8 +198,55 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
         split_stage<NL, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
-        if constexpr (CHECK == CHECK_EXACT) {
-            if (bad < 0 && point_nonfinite()) bad = step_index;
+    };
+    auto rk4_step = [&](const int) { rk4_step_on(y, Er, Ei); };
+    auto seed_on = [&](const int step, double &er, double &ei) {
+        double c, s;
+        Phase<double>::eval(dbd * ((double)step * hd), c, s);
+        er = e_amp * c;
+        ei = e_amp * s;
+    };
+
+    // CHECK_EXACT by replay (see rk4_sweep_kernel): state at the last test point; a wave with a newly failing point repeats
+    // the steps since then on a copy, testing after each one.  Both lanes of a point take the branch together (the test
+    // exchanges their partial sums), and the replay's own exchanges stay within the pair.
+    constexpr bool REPLAY = CHECK == CHECK_EXACT;
+    double y_chk[REPLAY ? NC : 1], Er_chk = 0.0, Ei_chk = 0.0;
+    int i_chk = 0, ss_chk = RESYNC;
+    auto checkpoint = [&](const int step, const int since_seed) {
+        if constexpr (REPLAY) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) y_chk[c] = y[c];
+            Er_chk = Er;
+            Ei_chk = Ei;
+            i_chk = step;
+            ss_chk = since_seed;
+        }
+    };
+    auto exact_test = [&](const int i_now, const int since_seed) {
+        if constexpr (REPLAY) {
+            const bool newly_bad = bad < 0 && point_nonfinite();
+            if (__builtin_amdgcn_ballot_w64(newly_bad) != 0) {
+                double yy[NC], er = Er_chk, ei = Ei_chk;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) yy[c] = y_chk[c];
+                int ii = i_chk, ss = ss_chk;
+                while (ii < i_now) {
+                    if (ss >= RESYNC) {
+                        seed_on(ii, er, ei);
+                        ss = 0;
+                    }
+                    const int e = (i_now - ii > RESYNC / 2) ? ii + RESYNC / 2 : i_now;
+#pragma nounroll
+                    for (int st = ii; st < e; ++st) {
+                        rk4_step_on(yy, er, ei);
+                        if (bad < 0 && nonfinite_on(yy)) bad = st;
+                    }
+                    ss += e - ii;
+                    ii = e;
+                }
+            }
+            checkpoint(i_now, since_seed);
         }
     };
 
@@ -227,9 +276,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
         split_stage<NL, LOSS>(Y4, t, Er, Ei, g_d, tg_d, ha_d, D);
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] = fma_(D[c], third, y[c]);
-        if constexpr (CHECK == CHECK_EXACT) {
-            if (bad < 0 && point_nonfinite()) bad = step_index;
-        }
+        (void)step_index;
     };
 #endif
 
@@ -240,24 +287,21 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
             auto save_row = [&](const int r) {
                 pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
                 pm = pe > pm ? pe : pm;               // NaN is made to propagate after the loop (it is sticky in y)
-                if constexpr (CHECK == CHECK_BLOCK) {
+                if constexpr (CHECK != CHECK_NONE) {      // a row is a step here: exact in either mode
                     if (bad < 0 && point_nonfinite()) bad = r - 1;
                 }
                 store_traj_row(r);
             };
             int i = 0;
             while (i < n_run) {
-                double c, s;
-                Phase<double>::eval(dbd * ((double)i * hd), c, s);
-                Er = e_amp * c;
-                Ei = e_amp * s;
+                seed_on(i, Er, Ei);
                 const int end = (n_run - i > RESYNC) ? i + RESYNC : n_run;
 #ifdef PSA_SPLIT_TRAJ_SPREAD
                 for (; i < end; ++i) {      // row i was "saved" (summary only) after step i-1; its stores ride in step i
                     if (i == 0) rk4_step(0); else rk4_step_spread(i, i);
                     pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
                     pm = pe > pm ? pe : pm;
-                    if constexpr (CHECK == CHECK_BLOCK) {
+                    if constexpr (CHECK != CHECK_NONE) {
                         if (bad < 0 && point_nonfinite()) bad = i;
                     }
                 }
@@ -292,12 +336,10 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     constexpr int CHUNK = RESYNC / 2;
     int i = 0, since_seed = RESYNC, row = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    checkpoint(0, since_seed);
     while (i < n_run) {
         if (since_seed >= RESYNC) {
-            double c, s;
-            Phase<double>::eval(dbd * ((double)i * hd), c, s);
-            Er = e_amp * c;
-            Ei = e_amp * s;
+            seed_on(i, Er, Ei);
             since_seed = 0;
         }
         int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
@@ -318,6 +360,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
             if constexpr (CHECK == CHECK_BLOCK) {
                 if (bad < 0 && point_nonfinite()) bad = i - 1;
             }
+            exact_test(i, since_seed);
             if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {
                 store_a_end();
@@ -330,6 +373,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     if constexpr (CHECK == CHECK_BLOCK) {
         if (bad < 0 && n_run > 0 && point_nonfinite()) bad = n_run - 1;
     }
+    if (n_run > i_chk) exact_test(n_run, since_seed);   // the unsaved tail (CHECK_EXACT only)
     if (owns_signal) {
         A.p_end[idx] = pe;
         A.p_max[idx] = pm;

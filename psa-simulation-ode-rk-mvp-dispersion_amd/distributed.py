@@ -213,7 +213,7 @@ class DeviceSweep:
 
     def __init__(self, dbeta_local: Optional[np.ndarray] = None, *, n_steps: int, z_max: float, save_every: int,
                  gamma, alpha, a0: np.ndarray, dbeta2_local: Optional[np.ndarray] = None,
-                 n_local: Optional[int] = None, dtype=np.float64, check_nan: bool = True, exact_step: bool = False,
+                 n_local: Optional[int] = None, dtype=np.float64, check_nan: bool = True, exact_step: Optional[bool] = None,
                  device: Optional[torch.device] = None, extra_flags: int = 0, pad_to: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceSweep needs a GPU: libpsa_hip has no CPU fallback")
@@ -282,7 +282,7 @@ class DeviceSweep:
         self.traj = None    # optional [n_saved][n_waves][n_local][2] trajectory buffer (enable_trajectory)
         lossless = bool(bcast & _native.BCAST_ALPHA) and float(np.asarray(alpha).reshape(-1)[0]) == 0.0
         self.flags = (bcast | int(extra_flags) | (_native.OPT_CHECK_NAN if check_nan else 0)
-                      | (_native.OPT_EXACT_STEP if exact_step else 0) | (_native.OPT_LOSSLESS if lossless else 0))
+                      | (_native.OPT_EXACT_STEP if (check_nan and (exact_step or (exact_step is None and self.np_dtype == np.float64))) else 0) | (_native.OPT_LOSSLESS if lossless else 0))
         self._axes = {}
 
     @property

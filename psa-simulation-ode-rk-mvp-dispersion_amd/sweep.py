@@ -101,7 +101,7 @@ def _sweep_over_devices(devices, dbeta, **kw) -> dict:
 
 def rk4_sweep(dbeta, *, z_max: float, dz: Optional[float] = None, n_steps: Optional[int] = None,
               save_every: int = 10, check_nan: bool = True, gamma, alpha, a0, dbeta2=None, dtype=np.float64,
-              device: int = 0, exact_step: bool = False, want_traj: bool = False,
+              device: int = 0, exact_step: Optional[bool] = None, want_traj: bool = False,
               devices: Optional[Sequence[int]] = None) -> SweepResult:
     """Propagate N points.  ``dz`` gives n = int(round(z_max/dz)) as integrators.py:194; or pass ``n_steps``.
     ``devices=[0, 1, ...]`` splits the points over several GPUs of this process (one thread per device)."""

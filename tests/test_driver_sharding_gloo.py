@@ -185,7 +185,7 @@ def test_drivers_shard_over_the_process_group_and_every_rank_gets_the_whole_swee
     assert r0["six.a_end"].shape == (5, 7, 6) and (r0["six.bad"] == -1).all()
 
 
-def test_devices_list_splits_the_points_over_threads(monkeypatch):
+def test_devices_list_splits_the_points_over_threads():
     """devices=[...] (a plain Python caller, no process group): contiguous blocks, one thread per device, results in order."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import psa_amd._native as nat
@@ -198,7 +198,7 @@ def test_devices_list_splits_the_points_over_threads(monkeypatch):
     def spy(dbeta, *, device=0, **kw):
         seen.append((int(device), len(dbeta)))
         return inner(dbeta, device=device, **kw)
-    monkeypatch.setattr(nat, "sweep_host", spy)
+    nat.sweep_host = spy
     try:
         rng = np.random.default_rng(2)
         db, gam = np.linspace(-0.04, 0.04, 11), rng.uniform(5e-3, 2e-2, 11)

@@ -6,7 +6,7 @@
 # The program itself follows `--` (python3 bench.py ...): no env/bash hop under the profiler; counters never share a run with
 # a trace domain other than --kernel-trace.
 # Usage: tools/profile_r03.sh <out-dir> <cfg> [<cfg> ...]
-#   cfg in  c2 c2x (--exact-step) c3 c4 c5 c5one  traj trajf32 traj6 traj4s traj6s
+#   cfg in  c2 c2blk (--block-check) c3 c4 c5 c5one  traj trajf32 traj6 traj4s traj6s
 set -e
 export TMPDIR=/tmp
 OUT=$1; shift
@@ -15,7 +15,7 @@ for cfg in "$@"; do
   F64=1
   case $cfg in
     c2)      ARGS="--config c2 --steps 5 --warmup 1 --no-cpu-baseline" ;;
-    c2x)     ARGS="--config c2 --exact-step --steps 5 --warmup 1 --no-cpu-baseline" ;;
+    c2blk)   ARGS="--config c2 --block-check --steps 5 --warmup 1 --no-cpu-baseline" ;;
     c3)      ARGS="--config c3 --steps 2 --warmup 1 --no-cpu-baseline" ;;
     c4)      ARGS="--config c4 --steps 2 --warmup 1 --no-cpu-baseline"; F64=0 ;;
     c5)      ARGS="--config c5 --steps 5 --warmup 1 --no-cpu-baseline" ;;

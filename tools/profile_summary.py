@@ -18,12 +18,12 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_Z = {"c2": 100_000, "c2x": 100_000, "c3": 100_000, "c4": 1_000_000, "c5": 100_000, "c5one": 100_000, "traj": 400,
+N_Z = {"c2": 100_000, "c2blk": 100_000, "c3": 100_000, "c4": 1_000_000, "c5": 100_000, "c5one": 100_000, "traj": 400,
        "trajf32": 400, "traj6": 400, "traj4s": 3200, "traj6s": 2000}
-LANES_PER_POINT = {"c2": 1.0, "c2x": 1.0, "c3": 1.0, "c4": 0.5, "c5": 2.0, "c5one": 1.0, "traj": 1.0, "trajf32": 0.5, "traj6": 1.0,
+LANES_PER_POINT = {"c2": 1.0, "c2blk": 1.0, "c3": 1.0, "c4": 0.5, "c5": 2.0, "c5one": 1.0, "traj": 1.0, "trajf32": 0.5, "traj6": 1.0,
                    "traj4s": 2.0, "traj6s": 2.0}
 KEY = {"traj": "trajectory", "trajf32": "traj_c4", "traj6": "traj_c5", "traj4s": "traj_c2split", "traj6s": "traj_c5split",
-       "c2x": "c2_exact_step"}
+       "c2blk": "c2_block_check"}
 
 
 def one(pattern):

@@ -7,7 +7,7 @@ set -e
 O=gpurun_out/${1:-r3all}
 mkdir -p $O
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-python3 bench.py --exact-step --no-cpu-baseline > $O/bench_c2_exact_step.json 2> $O/bench_c2_exact_step.err
+python3 bench.py --block-check --no-cpu-baseline > $O/bench_c2_block_check.json 2> $O/bench_c2_block_check.err
 python3 bench.py --config c3 --steps 4 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err
 python3 bench.py --config c4 --steps 4 --warmup 1 > $O/bench_c4.json 2> $O/bench_c4.err
 python3 bench.py --config c5 > $O/bench_c5.json 2> $O/bench_c5.err

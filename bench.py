@@ -320,6 +320,10 @@ def main() -> None:
                     help="the reference's per-step finite test (integrators.py:132-135).  Default for the float64 workloads, "
                          "where the exact first_bad_step costs nothing in the loop (block test + replay of a failing block); "
                          "for float32 (c4) this flag turns on the packed kernel's in-loop test")
+    ap.add_argument("--d2h", choices=["overlap", "inline", "off"], default="overlap",
+                    help="how a pass's outputs reach pinned host memory inside the timed region: on a second stream under the "
+                         "next pass's kernel (default), on the launch stream (A/B), or not at all (outputs left in HBM: the "
+                         "round-1/2 clock, NOT the metric's)")
     ap.add_argument("--block-check", action="store_true", help="float64: test once per saved row only (first_bad_step = the "
                                                                 "last step of the first non-finite block)")
     args = ap.parse_args()
@@ -397,7 +401,8 @@ def main() -> None:
         g = sweep.gather() if use_dist else None
         if evs is not None:
             evs[2].record()
-        sweep.stage_to_host(g)
+        if args.d2h != "off":
+            sweep.stage_to_host(g, overlap=(args.d2h == "overlap"))
         return g
 
     for _ in range(args.warmup):
@@ -422,6 +427,9 @@ def main() -> None:
         wall = float(tw.item())
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     resident_ms = float(np.mean([e[0].elapsed_time(e[2]) for e in events]))   # launch .. gain (.. gather), outputs left in HBM
+    if args.d2h == "off":
+        sweep.stage_to_host(gathered)              # after the clock has stopped: the guard below reads the host image
+        torch.cuda.synchronize()
     host_words, host_summ = sweep.host_result()
 
     # -- post-run guard (not timed): the numbers just produced are the right numbers
@@ -503,7 +511,9 @@ def main() -> None:
             # the clock of `value`: launch -> gain reduction -> (gather) -> outputs complete in pinned host memory,
             # the copy of pass k overlapped with the kernel of pass k+1 on a second stream.  The figure with the outputs
             # left in HBM (launch .. gather, HIP events on the launch stream) is kept beside it:
-            "value_clock": "kernel launch to completed D2H of the outputs (and completed gather), K passes back to back",
+            "value_clock": ("kernel launch to completed D2H of the outputs (and completed gather), K passes back to back"
+                            if args.d2h != "off" else "DEVICE-RESIDENT (--d2h off): outputs left in HBM, not the metric's clock"),
+            "d2h": args.d2h,
             "value_device_resident": updates_per_step / (resident_ms * 1e-3),   # rank 0's events
             "device_resident_ms_per_step": resident_ms,
             "d2h_bytes_per_step": int(host_words.nbytes + sum(t.nbytes for t in host_summ)),

@@ -11,4 +11,4 @@ Module names mirror the reference (config, simulation, integrators, yaman_model,
 frequency_plan, phase_matching, dispersion, parameters, constants).  All numerics run in
 ``libpsa_hip.so`` (hand-written HIP for gfx950) through ``_native``; there is no CPU fallback.
 """
-__version__ = "0.2.0"
+__version__ = "0.3.0"

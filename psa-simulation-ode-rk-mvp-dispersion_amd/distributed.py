@@ -377,15 +377,18 @@ class DeviceSweep:
         with torch.cuda.device(self.device):
             return _all_gather_words(self.record, world, group, out=self._gathered[b])
 
-    def stage_to_host(self, gathered: Optional[torch.Tensor] = None) -> None:
+    def stage_to_host(self, gathered: Optional[torch.Tensor] = None, overlap: bool = True) -> None:
         """Enqueue the device-to-host copy of the latest pass's outputs -- the record (or ``gathered``, every rank's) and,
         if ``summarize`` ran, the gains and the argmax -- into pinned host memory on a SECOND stream, then switch to the
         other record so that the next launch can start at once: the copy of pass k rides under the kernel of pass k + 1.
         Stream order is kept by events both ways (copy after the producers of pass k; the launch that reuses a buffer
-        after the copy that read it).  ``host_result()`` returns the image after a synchronize."""
+        after the copy that read it).  ``host_result()`` returns the image after a synchronize.  ``overlap=False`` puts the
+        copy on the launch stream itself (A/B: no second queue, the copy then sits between two kernels)."""
         b = self._last
         cur = torch.cuda.current_stream(self.device)
-        if self._copy_stream is None:
+        if not overlap:
+            self._copy_stream = cur
+        elif self._copy_stream is None or self._copy_stream == cur:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         if len(self._records) == 1:
             self._records.append(torch.zeros_like(self._records[0]))

@@ -22,6 +22,8 @@ N_Z = {"c2": 100_000, "c2blk": 100_000, "c3": 100_000, "c4": 1_000_000, "c5": 10
        "trajf32": 400, "traj6": 400, "traj4s": 3200, "traj6s": 2000}
 LANES_PER_POINT = {"c2": 1.0, "c2blk": 1.0, "c3": 1.0, "c4": 0.5, "c5": 2.0, "c5one": 1.0, "traj": 1.0, "trajf32": 0.5, "traj6": 1.0,
                    "traj4s": 2.0, "traj6s": 2.0}
+N_PTS = {"c2": 65_536, "c2blk": 65_536, "c3": 1_048_576, "c4": 131_072, "c5": 32_768, "c5one": 32_768, "traj": 262_144,
+         "trajf32": 524_288, "traj6": 262_144, "traj4s": 32_768, "traj6s": 32_768}
 KEY = {"traj": "trajectory", "trajf32": "traj_c4", "traj6": "traj_c5", "traj4s": "traj_c2split", "traj6s": "traj_c5split",
        "c2blk": "c2_block_check"}
 
@@ -108,22 +110,31 @@ def main(src, tag):
                     v = list(per.values())
                     w.writerow([kernel, name, len(v), statistics.median(v), min(v), max(v)])
             med = {k: statistics.median(list(v.values())) for k, v in counters.items()}
+            low = {k: min(v.values()) for k, v in counters.items()}
             rec["counters_median"] = med
-            if "SQ_INSTS_VALU" in med and med.get("SQ_WAVES"):
-                rec["valu_insts_per_wave_step"] = med["SQ_INSTS_VALU"] / med["SQ_WAVES"] / N_Z[cfg]
-                rec["waves"] = med["SQ_WAVES"]
+            # waves of one launch = what the grid asks for.  SQ_WAVES can exceed it: bench.py copies pass k's outputs to the
+            # host on a second stream under pass k+1's kernel, and for shards that fill the chip several times over (c3) the
+            # hardware scheduler context-switches the resident waves once per pass to serve that queue (compute wave
+            # save/restore): the restored waves are counted again and their register image shows up in FETCH / WRITE_SIZE.
+            # Per-wave figures are therefore normalised by the grid's wave count, and the kernel's OWN traffic is read from
+            # the dispatch that was not switched (the minimum); the switched one is kept as cwsr_bytes_per_launch.
+            waves = -(-int(round(N_PTS[cfg] * LANES_PER_POINT[cfg])) // 64)
+            rec["waves"] = float(waves)
+            if "SQ_INSTS_VALU" in med:
+                rec["valu_insts_per_wave_step"] = med["SQ_INSTS_VALU"] / waves / N_Z[cfg]
+            if med.get("SQ_WAVES") and max(counters["SQ_WAVES"].values()) > waves:
+                rec["sq_waves_max"] = max(counters["SQ_WAVES"].values())
             # executed floating-point work: wave-instruction counts of the FMA / MUL / ADD classes (an FMA = 2 flops per lane;
             # a packed float32 instruction does two per lane and is counted by SQ_INSTS_VALU_FLOPS_FP32 accordingly), per lane
             # per z-step.  The dedicated gfx950 counter SQ_INSTS_VALU_FLOPS_FP64/32 is kept beside the sum as a cross-check.
             for suf in ("F64", "F32"):
                 fma, mul, add = (med.get(f"SQ_INSTS_VALU_{k}_{suf}") for k in ("FMA", "MUL", "ADD"))
-                if fma is None or not med.get("SQ_WAVES") and not rec.get("waves"):
+                if fma is None:
                     continue
                 if suf == "F32" and cfg not in ("c4", "trajf32"):
                     continue
                 if suf == "F64" and cfg in ("c4", "trajf32"):
                     continue
-                waves = rec.get("waves") or med.get("SQ_WAVES")
                 per_wave_step = (2 * fma + (mul or 0) + (add or 0)) / waves / N_Z[cfg]
                 pack = 2.0 if suf == "F32" else 1.0          # v_pk_* : one wave-instruction = two lanes' worth per lane
                 rec["executed_flops_per_lane_step"] = per_wave_step * pack
@@ -136,9 +147,12 @@ def main(src, tag):
                 dur = statistics.median(list(durations["grbm"].values()))
                 rec["held_clock_ghz"] = med["GRBM_GUI_ACTIVE"] / 8 / (dur * 1e-3) / 1e9
             if "FETCH_SIZE" in med and "WRITE_SIZE" in med:
-                rec["fetch_bytes_corrected"] = med["FETCH_SIZE"] * 1024 * 2
-                rec["write_bytes"] = med["WRITE_SIZE"] * 1024
+                rec["fetch_bytes_corrected"] = low["FETCH_SIZE"] * 1024 * 2
+                rec["write_bytes"] = low["WRITE_SIZE"] * 1024
                 rec["hbm_bytes_per_launch"] = rec["fetch_bytes_corrected"] + rec["write_bytes"]
+                switched = max(counters["FETCH_SIZE"].values()) * 2048 + max(counters["WRITE_SIZE"].values()) * 1024
+                if switched > 1.5 * rec["hbm_bytes_per_launch"]:
+                    rec["cwsr_bytes_per_launch"] = switched - rec["hbm_bytes_per_launch"]
                 rec["traffic_correction"] = ("MI355X_MICROARCH.md HBM section: bytes = counter x 1024; FETCH_SIZE doubled on "
                                              "gfx950 (128-B requests tallied at 64 B)")
         facts[KEY.get(cfg, cfg)] = rec

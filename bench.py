@@ -405,6 +405,8 @@ def main() -> None:
             sweep.stage_to_host(g, overlap=(args.d2h == "overlap"))
         return g
 
+    if args.d2h != "off":
+        sweep.reserve_staging(world if use_dist else 1)      # page-locked images, second record: never inside the clock
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()

@@ -412,6 +412,30 @@ class DeviceSweep:
         if self._copied[self._cur] is not None:      # the pass before last read this buffer: long done, but say so
             cur.wait_event(self._copied[self._cur])
 
+    def reserve_staging(self, world: int = 1, with_summary: bool = True) -> None:
+        """Allocate everything ``summarize`` / ``gather`` / ``stage_to_host`` would otherwise create on first use -- the
+        second record, the copy stream, both gathered buffers (``world`` > 1), both pinned host images and the summary
+        buffers -- so that no allocation (page-locking hundreds of MB takes ~0.1 s) falls into a timed region."""
+        if len(self._records) == 1:
+            self._records.append(torch.zeros_like(self._records[0]))
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        n_words = self._records[0].numel() * (world if world > 1 else 1)
+        for b in (0, 1):
+            if world > 1 and (self._gathered[b] is None or self._gathered[b].shape[0] != world):
+                self._gathered[b] = torch.empty((world, self._records[0].numel()), dtype=torch.int64, device=self.device)
+            if self._host[b] is None or self._host[b].numel() != n_words:
+                self._host[b] = torch.empty(n_words, dtype=torch.int64, pin_memory=True)
+            if with_summary:
+                if self._summ[b] is None:
+                    self._summ[b] = (torch.empty(self.n_local, dtype=self.tdtype, device=self.device),
+                                     torch.zeros(2, dtype=torch.int64, device=self.device),
+                                     torch.zeros(1, dtype=torch.float64, device=self.device))
+                if self._host_gain[b] is None:
+                    self._host_gain[b] = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self._summ[b])
+        if with_summary and self._ws is None:
+            self._ws = torch.empty(_native.gain_summary_workspace_bytes(self.n_local), dtype=torch.uint8, device=self.device)
+
     def host_result(self):
         """(words, (gain, best, best_gain) | None) of the latest staged pass as NumPy views of the pinned buffers.
         The caller synchronizes first (``torch.cuda.synchronize`` or the event in ``_copied``)."""

@@ -206,7 +206,10 @@ def test_failure_in_the_unsaved_tail_is_seen_only_with_check_nan(oracle):
                          exact_step=True)
     assert got["first_bad_step"][0] == 2
     assert np.array_equal(got["a_end"][0], A0) and got["p_max"][0] == got["p_end"][0] == abs(A0[2]) ** 2
-    blk = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=True)
+    dflt = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=True)
+    assert dflt["first_bad_step"][0] == 2                     # float64 default: the exact index (free, by replay)
+    blk = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=True,
+                         exact_step=False)
     assert blk["first_bad_step"][0] == 3                      # block mode: last step of the (partial) block
     off = nat.sweep_host([0.01], n_steps=4, z_max=0.4, save_every=10, gamma=12.0, alpha=0.0, a0=A0, check_nan=False)
     assert off["first_bad_step"][0] == -1 and np.isfinite(off["p_max"][0])

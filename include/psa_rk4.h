@@ -85,6 +85,12 @@ extern "C" {
                                             instruction stream per lane.  Default: chosen automatically when the sweep is
                                             smaller than the chip (2*N lanes still get one SIMD per wave: N <= 32 768).   */
 #define PSA_OPT_ONE_LANE     (1u << 16)  /* float64 only: never split a point over two lanes                              */
+#define PSA_OPT_TRAJ_LD      (1u << 17)  /* `_dev` entry points: the trajectory buffer is [n_saved][n_waves][ld][2] with the
+                                            leading dimension ld = psa_traj_ld(n_points, sizeof(element)) >= n_points
+                                            instead of n_points: sizes whose wave regions would lie a multiple of 2 MiB
+                                            apart are padded by 4 352 B, which lifts the store rate of every-step
+                                            trajectories by 8-35 %.  The host-buffer entry points use
+                                            it internally; the caller's array stays dense.                          */
 #define PSA_OPT_F32_SCALAR   (1u << 12)  /* float32 only: force one sweep point per lane                          */
 #define PSA_OPT_F32_PACKED   (1u << 13)  /* float32 only: force two points per lane (v_pk_fma_f32 packed math);
                                             this is also the default whenever n_points >= 2                      */
@@ -94,6 +100,7 @@ int         psa_device_count(void);          /* number of visible HIP devices (0
 const char *psa_last_error(void);            /* message of the last failure on this thread            */
 const char *psa_version(void);               /* "psa-hip <semver> gfx950"                              */
 int64_t     psa_n_saved(int64_t n_steps, int32_t save_every);   /* n_steps / save_every + 1, integrators.py:115 */
+int64_t     psa_traj_ld(int64_t n_points, int32_t elem_size);   /* leading dimension for PSA_OPT_TRAJ_LD (elem_size 4 | 8) */
 int         psa_release_cache(void);         /* destroy the idle call contexts of every device; returns how many       */
 
 /* ---- B3/B2: the sweep (host buffers, blocking) ----------------------------------

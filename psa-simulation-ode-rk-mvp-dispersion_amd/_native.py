@@ -36,6 +36,7 @@ OPT_F32_PACKED = 1 << 13
 OPT_LOSSLESS = 1 << 14
 OPT_SPLIT_POINT = 1 << 15
 OPT_ONE_LANE = 1 << 16
+OPT_TRAJ_LD = 1 << 17
 MAX_POINTS = 2**31 - 256          # PSA_MAX_POINTS: the most points one launch takes
 
 # every symbol the header declares, with (restype, argtypes)
@@ -46,6 +47,7 @@ _SIGS = {
     "psa_version": (C.c_char_p, []),
     "psa_n_saved": (C.c_int64, [C.c_int64, C.c_int32]),
     "psa_release_cache": (C.c_int, []),
+    "psa_traj_ld": (C.c_int64, [C.c_int64, C.c_int32]),
     "psa_rk4_sweep_f64": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
                                     _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "psa_rk4_sweep_f32": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_int32,
@@ -144,6 +146,11 @@ def device_count() -> int:
 
 def version() -> str:
     return lib().psa_version().decode()
+
+
+def traj_ld(n_points: int, dtype=np.float64) -> int:
+    """Leading dimension of a device trajectory buffer launched with OPT_TRAJ_LD (psa_traj_ld)."""
+    return int(lib().psa_traj_ld(int(n_points), int(np.dtype(dtype).itemsize)))
 
 
 def release_cache() -> int:

@@ -38,6 +38,18 @@ int hip_fail(hipError_t e, const char *what) {
         if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto done; } \
     } while (0)
 
+// Leading dimension of the trajectory buffer [n_saved][n_waves][ld][2].  The four (six) wave regions of a row, and
+// consecutive rows, are ld * pair bytes apart; when that is a multiple of 2 MiB the streams of the resident waves collide in
+// the memory system's address hash and the store rate drops (store-only probe, tools/hbm_write_peak: 5.7 / 5.6 / 4.9 TB/s at
+// 262 144 / 524 288 / 1 048 576 points against 6.3 / 6.5 / 6.6 with the regions 4 352 B further apart; sizes that are not
+// such multiples, and strides of 1 MiB or less, are best left alone: profiles/r03_store_layout_probe.log).
+int64_t traj_ld_of(int64_t n_points, size_t elem_size) {
+    const int64_t pair = 2 * (int64_t)elem_size;
+    const int64_t bytes = n_points * pair;
+    if (n_points <= 0 || bytes % (2ll << 20) != 0) return n_points;
+    return n_points + 4352 / pair;          // 17 x 256 B: 272 float64 points, 544 float32 points
+}
+
 int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max, int32_t save_every,
                     const void *dbeta, const void *dbeta2, const void *gamma, const void *alpha, const void *a0,
                     const void *a_end, const void *p_end, const void *p_max, const void *first_bad, uint32_t flags,
@@ -66,7 +78,8 @@ int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max
         if ((unsigned long long)n_points * pair >= (1ull << 31))
             return fail(PSA_E_TOO_LARGE, "a trajectory launch takes at most %llu points", (1ull << 31) / pair - 1);
         // the two-lane layout folds the lane's wave offset into that 32-bit offset
-        if ((flags & PSA_OPT_SPLIT_POINT) && (unsigned long long)n_points * n_waves * pair >= (1ull << 32))
+        const unsigned long long ld = (flags & PSA_OPT_TRAJ_LD) ? (unsigned long long)traj_ld_of(n_points, elem_size) : (unsigned long long)n_points;
+        if ((flags & PSA_OPT_SPLIT_POINT) && ld * n_waves * pair >= (1ull << 32))
             return fail(PSA_E_TOO_LARGE, "a two-lane trajectory launch takes at most %llu points",
                         (1ull << 32) / (n_waves * pair) - 1);
     }
@@ -93,6 +106,7 @@ psa::SweepArgs<T> make_args(int n_waves, int64_t n_points, int64_t n_steps, doub
     a.p_max = p_max;
     a.first_bad = (long long *)first_bad;
     a.traj = traj;
+    a.traj_ld = (flags & PSA_OPT_TRAJ_LD) ? traj_ld_of(n_points, sizeof(T)) : n_points;
     a.n_points = n_points;
     a.z_max = z_max;
     a.n_steps = (int)n_steps;
@@ -315,12 +329,15 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
     const int nc = 2 * n_waves;
     const size_t N = (size_t)n_points;
     const int64_t n_saved = n_steps / save_every + 1;
+    // the device-side trajectory buffer has its own leading dimension (traj_ld_of); the caller's array is dense
+    const size_t ld = (size_t)traj_ld_of(n_points, sizeof(T));
     size_t traj_elems = 0;
     if (traj) {
-        // N * n_saved * nc must fit comfortably in int64 / size_t
-        const long double te = (long double)N * (long double)n_saved * (long double)nc;
+        // ld * n_saved * nc must fit comfortably in int64 / size_t
+        const long double te = (long double)ld * (long double)n_saved * (long double)nc;
         if (te > 4.0e18L) return fail(PSA_E_TOO_LARGE, "trajectory buffer too large");
-        traj_elems = N * (size_t)n_saved * (size_t)nc;
+        traj_elems = ld * (size_t)n_saved * (size_t)nc;
+        flags |= PSA_OPT_TRAJ_LD;
     }
     if ((flags & PSA_BCAST_ALPHA) && alpha[0] == T(0)) flags |= PSA_OPT_LOSSLESS;   // the reference's alpha == 0.0 branch
     const size_t n_gamma = (flags & PSA_BCAST_GAMMA) ? 1 : N;
@@ -453,7 +470,7 @@ int sweep_host(int device, int n_waves, int64_t n_points, int64_t n_steps, doubl
             if (injected_chunk_failure(p0 / chunk_pts)) return hip_fail(hipErrorUnknown, "injected failure in the staging loop");
 #endif
             // stream order on st_copy[b] keeps the staging buffer busy until its previous copy has finished
-            HIP_RET(Launch<T>::t2a(cx.st_copy[b], d_traj + 2 * p0, d_stage[b], (long long)pts, (long long)N,
+            HIP_RET(Launch<T>::t2a(cx.st_copy[b], d_traj + 2 * p0, d_stage[b], (long long)pts, (long long)ld,
                                    (long long)n_saved, nc));
             HIP_RET(hipMemcpyAsync(traj + p0 * (size_t)n_saved * nc, d_stage[b], pts * point_bytes, hipMemcpyDeviceToHost,
                                    cx.st_copy[b]));
@@ -647,6 +664,10 @@ const char *psa_version(void) { return "psa-hip 0.3.0 gfx950"; }
 int64_t psa_n_saved(int64_t n_steps, int32_t save_every) {
     if (n_steps < 0 || save_every <= 0) return -1;
     return n_steps / save_every + 1;
+}
+int64_t psa_traj_ld(int64_t n_points, int32_t elem_size) {
+    if (n_points < 0 || (elem_size != 4 && elem_size != 8)) return -1;
+    return traj_ld_of(n_points, (size_t)elem_size);
 }
 int psa_release_cache(void) {
     std::vector<HostCtx *> idle;

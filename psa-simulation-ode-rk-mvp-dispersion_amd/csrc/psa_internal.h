@@ -18,7 +18,8 @@ struct SweepArgs {
     T *p_end;            // [N]
     T *p_max;            // [N]
     long long *first_bad;  // [N]
-    T *traj;             // [n_saved][NW][N][2] ((re, im) pairs) or nullptr
+    T *traj;             // [n_saved][NW][traj_ld][2] ((re, im) pairs) or nullptr
+    long long traj_ld;   // points per (row, wave) region of traj: n_points, or padded (psa_traj_ld)
     long long n_points;
     double z_max;
     int n_steps;

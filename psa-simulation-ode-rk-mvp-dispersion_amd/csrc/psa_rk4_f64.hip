@@ -49,7 +49,7 @@ hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int
     const int simds = simd_count(s);
     const long long split_waves = (2 * a.n_points + 63) / 64;
     // a two-lane trajectory launch folds the lane's wave offset into the 32-bit store offset: NW * N * 16 B < 2^32
-    const bool split_ok = !lds && (a.traj == nullptr || (unsigned long long)a.n_points * n_waves * 16ull < (1ull << 32));
+    const bool split_ok = !lds && (a.traj == nullptr || (unsigned long long)a.traj_ld * n_waves * 16ull < (1ull << 32));
     const bool use_split = split_ok && (split == 1 || (split < 0 && split_is_faster(n_waves, a.n_points, simds)));
     if (use_split) {
         const int sb = (block == 64 || 2 * split_waves <= (long long)simds) ? 64 : 256;   // see launch_sweep_split

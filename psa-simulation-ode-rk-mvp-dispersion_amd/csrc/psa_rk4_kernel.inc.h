@@ -225,12 +225,13 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     // (global_store ... saddr form): no vector instruction is spent on addressing.  The C-ABI keeps N * sizeof(Pair) < 2^32
     // for trajectory launches.
     using Pair = typename PairOf<T>::type;
+    const long long LD = A.traj_ld;   // points per (row, wave) region: N, or N padded off a power of two (psa_traj_ld)
     const unsigned lane_off = (unsigned)idx * (unsigned)sizeof(Pair);
     auto store_traj_row = [&](const int r) {
-        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * LD * (long long)sizeof(Pair);
 #pragma unroll
         for (int j = 0; j < NW; ++j)
-            store_pair_nt(rowb + (long long)j * N * (long long)sizeof(Pair), lane_off, Pair{y[2 * j], y[2 * j + 1]});
+            store_pair_nt(rowb + (long long)j * LD * (long long)sizeof(Pair), lane_off, Pair{y[2 * j], y[2 * j + 1]});
     };
     if constexpr (TRAJ) store_traj_row(0);
     if (n_rows == 0) {

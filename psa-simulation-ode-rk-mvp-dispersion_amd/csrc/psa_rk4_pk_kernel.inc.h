@@ -131,17 +131,18 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     // trajectory rows [row][wave][N][2]: the lane's two points are adjacent, so each wave of the model is ONE 16-B streaming
     // store per lane (1 KiB per wave instruction); the (row, wave) part of the address stays in SGPRs and the lane adds a
     // 32-bit byte offset (the C-ABI keeps N * 8 B < 2^31 for trajectory launches), exactly as rk4_sweep_kernel does.
+    const long long LD = A.traj_ld;   // points per (row, wave) region (psa_traj_ld)
     const unsigned lane_off = (unsigned)idx * 16u;
     auto store_traj_row = [&](const int r) {
-        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * 8;
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * LD * 8;
         if (wave_full) {
 #pragma unroll
             for (int j = 0; j < NW; ++j)
-                store_quad_nt(rowb + (long long)j * N * 8, lane_off, (f32x4){y[2 * j].x, y[2 * j + 1].x, y[2 * j].y, y[2 * j + 1].y});
+                store_quad_nt(rowb + (long long)j * LD * 8, lane_off, (f32x4){y[2 * j].x, y[2 * j + 1].x, y[2 * j].y, y[2 * j + 1].y});
         } else {
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
-                const char *wb = rowb + (long long)j * N * 8;
+                const char *wb = rowb + (long long)j * LD * 8;
                 store_pair_nt(wb, lane_off, (f32x2){y[2 * j].x, y[2 * j + 1].x});
                 if (live1) store_pair_nt(wb, lane_off + 8u, (f32x2){y[2 * j].y, y[2 * j + 1].y});
             }

@@ -154,24 +154,25 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     // (role * R_j * N + idx) * 16 -- the global_store saddr form of rk4_sweep_kernel, no vector instruction spent on
     // addressing inside the z-loop.  (The C-ABI keeps NW * N * 16 B < 2^32 for two-lane trajectory launches.)
     using Pair = typename PairOf<double>::type;
+    const long long LD = A.traj_ld;   // points per (row, wave) region (psa_traj_ld)
     unsigned lane_off[NL];
     int wave_u[NL];
     if constexpr (NL == 2) {
         wave_u[0] = 0;
         wave_u[1] = 1;
-        lane_off[0] = lane_off[1] = (unsigned)((unsigned long long)(role * 2 * N + idx) * sizeof(Pair));
+        lane_off[0] = lane_off[1] = (unsigned)((unsigned long long)(role * 2 * LD + idx) * sizeof(Pair));
     } else {
         wave_u[0] = 0;
         wave_u[1] = 2;
         wave_u[2] = 3;
-        lane_off[0] = (unsigned)((unsigned long long)(role * N + idx) * sizeof(Pair));
-        lane_off[1] = lane_off[2] = (unsigned)((unsigned long long)(role * 2 * N + idx) * sizeof(Pair));
+        lane_off[0] = (unsigned)((unsigned long long)(role * LD + idx) * sizeof(Pair));
+        lane_off[1] = lane_off[2] = (unsigned)((unsigned long long)(role * 2 * LD + idx) * sizeof(Pair));
     }
     auto store_traj_row = [&](const int r) {
-        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * LD * (long long)sizeof(Pair);
 #pragma unroll
         for (int j = 0; j < NL; ++j)
-            store_pair_nt(rowb + (long long)wave_u[j] * N * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
+            store_pair_nt(rowb + (long long)wave_u[j] * LD * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
     };
     auto store_a_end = [&]() {
 #pragma unroll
@@ -257,8 +258,8 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     // non-temporal stores (1.64 / 1.56): with one wave per SIMD a store that finds the queue full stalls the only wave,
     // wherever in the step it is issued.  Not compiled in.
     auto store_traj_wave = [&](const int r, const int j) {
-        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * N * (long long)sizeof(Pair);
-        store_pair_nt(rowb + (long long)wave_u[j] * N * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
+        const char *rowb = reinterpret_cast<const char *>(A.traj) + (long long)r * NW * LD * (long long)sizeof(Pair);
+        store_pair_nt(rowb + (long long)wave_u[j] * LD * (long long)sizeof(Pair), lane_off[j], Pair{y[2 * j], y[2 * j + 1]});
     };
     auto rk4_step_spread = [&](const int step_index, const int r_prev) {
         double Y2[NC], Y3[NC], Y4[NC], t[NC], D[NC];

@@ -333,7 +333,7 @@ class DeviceSweep:
                              d_gamma=self.gamma.data_ptr(), d_alpha=self.alpha.data_ptr(), d_a0_soa=self.a0_soa.data_ptr(),
                              flags=self.flags, d_a_end_soa=self._part("a_end"), d_p_end=self._part("p_end"),
                              d_p_max=self._part("p_max"), d_first_bad=self._part("first_bad"),
-                             d_traj_soa=(self.traj.data_ptr() if self.traj is not None else 0), dtype=self.np_dtype)
+                             d_traj_soa=(self._traj_full.data_ptr() if self.traj is not None else 0), dtype=self.np_dtype)
 
     def summarize(self, p0_sig: float, *, mode: str = "max", gain_db: bool = True) -> None:
         """Enqueue the gain reduction of the sweep drivers (scan_mismtach.py:376-389 + argmax) on the same stream:
@@ -356,10 +356,18 @@ class DeviceSweep:
                                     d_workspace=self._ws.data_ptr(), dtype=self.np_dtype)
 
     def enable_trajectory(self) -> int:
-        """Allocate the trajectory buffer [n_saved][n_waves][n_local][2] ((re, im) pairs) in HBM; returns its bytes."""
+        """Allocate the trajectory buffer [n_saved][n_waves][ld][2] ((re, im) pairs) in HBM, ld = psa_traj_ld(n_local) (the
+        point count, padded off a 2 MiB stride); ``self.traj`` is its [n_saved][n_waves][n_local][2] view.  Returns the
+        bytes of the rows proper."""
+        import os
         n_saved = self.n_steps // self.save_every + 1
-        self.traj = torch.empty((n_saved, self.n_waves, self.n_local, 2), dtype=self.tdtype, device=self.device)
-        return self.traj.numel() * self.traj.element_size()
+        dense = os.environ.get("PSA_TRAJ_DENSE", "0") == "1"      # A/B hook (tools/ab_traj_padding.sh): ld = n_local
+        ld = self.n_local if dense else _native.traj_ld(self.n_local, self.np_dtype)
+        self._traj_full = torch.empty((n_saved, self.n_waves, ld, 2), dtype=self.tdtype, device=self.device)
+        self.traj = self._traj_full[:, :, :self.n_local, :]
+        if not dense:
+            self.flags |= _native.OPT_TRAJ_LD
+        return n_saved * self.n_waves * self.n_local * 2 * self._traj_full.element_size()
 
     def gather(self, group=None) -> torch.Tensor:
         """One all_gather of the latest record over the process group -> (world, words(pad_to)) int64 on this GPU.  Every

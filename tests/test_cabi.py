@@ -37,7 +37,8 @@ def test_flag_values_match_the_header():
                       ("PSA_OPT_EXACT_STEP", nat.OPT_EXACT_STEP), ("PSA_OPT_LDS_STAGING", nat.OPT_LDS_STAGING),
                       ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64), ("PSA_OPT_F32_SCALAR", nat.OPT_F32_SCALAR),
                       ("PSA_OPT_F32_PACKED", nat.OPT_F32_PACKED), ("PSA_OPT_LOSSLESS", nat.OPT_LOSSLESS),
-                      ("PSA_OPT_SPLIT_POINT", nat.OPT_SPLIT_POINT), ("PSA_OPT_ONE_LANE", nat.OPT_ONE_LANE)):
+                      ("PSA_OPT_SPLIT_POINT", nat.OPT_SPLIT_POINT), ("PSA_OPT_ONE_LANE", nat.OPT_ONE_LANE),
+                      ("PSA_OPT_TRAJ_LD", nat.OPT_TRAJ_LD)):
         m = re.search(rf"#define\s+{name}\s+\(1u\s*<<\s*(\d+)\)", src)
         assert m and (1 << int(m.group(1))) == val, name
 
@@ -46,6 +47,9 @@ def test_n_saved_rule():
     L = nat.lib()
     assert L.psa_n_saved(1005, 10) == 101 and L.psa_n_saved(10, 2) == 6 and L.psa_n_saved(7, 10) == 1
     assert L.psa_n_saved(10, 0) == -1
+    # psa_traj_ld: padded only where the wave regions would be a multiple of 2 MiB apart
+    assert L.psa_traj_ld(131072, 8) == 131072 + 272 and L.psa_traj_ld(131072, 4) == 131072 and L.psa_traj_ld(262144, 4) == 262144 + 544
+    assert L.psa_traj_ld(65536, 8) == 65536 and L.psa_traj_ld(0, 8) == 0 and L.psa_traj_ld(-1, 8) == -1 and L.psa_traj_ld(8, 2) == -1
 
 
 def _call_dev(**over):

@@ -120,3 +120,38 @@ def test_two_lane_trajectory_through_the_device_api_with_an_odd_point_count(orac
                 assert rel_err(tr[:, :, i, 0] + 1j * tr[:, :, i, 1], A) < tol, (N, dtype, i)
             last = tr[-1, :, :, 0] + 1j * tr[-1, :, :, 1]
             assert np.array_equal(last.T.astype(res.a_end.dtype), res.a_end)
+
+
+def test_padded_trajectory_leading_dimension(oracle):
+    """Sizes whose (row, wave) regions would lie a multiple of 2 MiB apart get a device buffer with ld = N + 4 352 B worth of
+    points (psa_traj_ld) -- inside the host-buffer API (the caller's array stays dense) and, with
+    PSA_OPT_TRAJ_LD, in the device API.  131 072 float64 points and 262 144 float32 points are such sizes: rows of points at
+    the ends, around a chunk boundary of the host transpose and in the middle against the oracle, in every lane layout."""
+    import torch
+    from psa_amd.distributed import DeviceSweep
+    assert nat.traj_ld(131_072) == 131_072 + 272 and nat.traj_ld(262_144, np.float32) == 262_144 + 544
+    assert nat.traj_ld(65_536) == 65_536 and nat.traj_ld(100_000) == 100_000 and nat.traj_ld(1) == 1 and nat.traj_ld(0) == 0
+    assert nat.traj_ld(262_144) == 262_144 + 272 and nat.traj_ld(131_072, np.float32) == 131_072
+    a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
+    n = 5
+    for N, dtype, layouts, tol in ((131_072, np.float64, (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT), RTOL_F64),
+                                  (262_144, np.float32, (nat.OPT_F32_PACKED, nat.OPT_F32_SCALAR), RTOL_F32)):
+        db = np.linspace(-0.05, 0.05, N).astype(dtype)
+        pick = [0, 1, 63, 64, N // 2 - 1, N // 2, N - 2, N - 1]
+        rows = {i: oracle.integrate(a0, z_max=0.5, n=n, save_every=1, gamma=0.0115, alpha=1.15e-4, dbeta=float(db[i]))[1] for i in pick}
+        for flags in layouts:
+            got = nat.sweep_host(db, n_steps=n, z_max=0.5, save_every=1, gamma=0.0115, alpha=1.15e-4, a0=a0, dtype=dtype,
+                                 want_traj=True, extra_flags=flags)
+            assert got["traj"].shape == (N, n + 1, 4) and np.array_equal(got["traj"][:, -1, :], got["a_end"])
+            for i in pick:
+                assert rel_err(got["traj"][i].astype(complex), rows[i]) < tol, (N, flags, i)
+            ds = DeviceSweep(db, n_steps=n, z_max=0.5, save_every=1, gamma=0.0115, alpha=1.15e-4, a0=a0, dtype=dtype,
+                             extra_flags=flags)
+            ds.enable_trajectory()
+            assert ds._traj_full.shape[2] == nat.traj_ld(N, dtype) > N and ds.traj.shape[2] == N and ds.flags & nat.OPT_TRAJ_LD
+            ds.launch()
+            torch.cuda.synchronize()
+            tr = ds.traj[:, :, pick, :].cpu().numpy().astype(float)
+            for k, i in enumerate(pick):
+                assert rel_err(tr[:, :, k, 0] + 1j * tr[:, :, k, 1], rows[i]) < tol, (N, flags, i)
+            assert np.array_equal(got["a_end"], ds.result().a_end)

@@ -10,8 +10,8 @@
 // complex polynomial (no contraction to tile).  So the design rules here are
 //   * minimum DP instructions per step (298 for 4 waves; see the count in DESIGN.md),
 //   * no transcendental in the steady-state loop: E(z) = 2*gamma*exp(i*dbeta*z) is carried by a
-//     complex rotation per half step and re-seeded from an exact sincos once RESYNC steps have passed
-//     (checked between 32-step chunks: every <= 96 steps; drift ~2e-14, far inside the 1e-9 parity budget),
+//     complex rotation per half step and re-seeded from an exact sincos at every multiple of RESYNC steps
+//     (64 in float64: drift <= 128 multiplications ~1.4e-14, far inside the 1e-9 parity budget),
 //   * all per-lane arrays statically indexed and in VGPRs (178 for the bench instantiation: 2 waves/SIMD; capping
 //     at 168 (3 waves) or 128 (4 waves, 16 spilled) was measured no faster -- the loop is issue-bound),
 //   * wave-uniform control flow only (save stride, resync and NaN tracking never diverge),
@@ -40,13 +40,14 @@ template <> struct PairOf<float> { typedef float type __attribute__((ext_vector_
 // the lane offset to 64 bits inside the z-loop and then spends a v_lshl_add_u64 per store on the address.
 // HAZARD: on gfx90a / gfx940 / gfx950 a VMEM store of MORE than 64 bits of data must not be followed within two wait
 // states by a VALU instruction that overwrites the data VGPRs (LLVM's GCNHazardRecognizer inserts the s_nop for stores it
-// can see; it cannot see into inline assembly).  The 16-B forms therefore carry their own `s_nop 1`: without it the packed
+// can see; it cannot see into inline assembly).  The 16-B forms therefore carry their own two wait states (as two 4-byte
+// `s_nop 0`, so that the 8-byte encodings after them stay on 8-byte boundaries): without them the packed
 // float32 kernel, which assembles each store's four floats in a temporary it reuses at once, wrote corrupt rows.
 #ifndef PSA_TRAJ_F64_MOD      // A/B hook (tools/ab_build.sh): -DPSA_TRAJ_F64_MOD='""' = default (write-back) stores
 #define PSA_TRAJ_F64_MOD " nt"
 #endif
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<double>::type v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2" PSA_TRAJ_F64_MOD "\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" PSA_TRAJ_F64_MOD "\n\ts_nop 0\n\ts_nop 0" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned voff, const PairOf<float>::type v) {
     asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
@@ -54,7 +55,7 @@ __device__ __forceinline__ void store_pair_nt(const void *sbase, const unsigned 
 // two adjacent float32 points' (re, im) pairs in one 16-B store (the packed kernel: points 2i and 2i+1 share a lane)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_quad_nt(const void *sbase, const unsigned voff, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0\n\ts_nop 0" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
 // cos/sin of a float64 phase, delivered in the working precision.
@@ -63,8 +64,11 @@ template <> struct Phase<double> {
     static constexpr int RESYNC = 64;  // steps after which the rotation recurrence is re-seeded exactly
     static __device__ __forceinline__ void eval(double ph, double &c, double &s) { sincos(ph, &s, &c); }
 };
+#ifndef PSA_F32_RESYNC          // A/B hook (tools/ab_build_f32.sh)
+#define PSA_F32_RESYNC 16
+#endif
 template <> struct Phase<float> {
-    static constexpr int RESYNC = 16;
+    static constexpr int RESYNC = PSA_F32_RESYNC;
     // dbeta*z reaches 1e4..1e5 rad at 1e6 steps: reduce in f64, then an f32 sincos on [-pi, pi].
     static __device__ __forceinline__ void eval(double ph, float &c, float &s) {
         const double r = ph - 6.283185307179586 * rint(ph * 0.15915494309189535);
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     auto seed_phase = [&](const int step) { seed_phase_on(step, Er, Ei); };
 
     // ---- CHECK_EXACT for the float64 register variant: exact first_bad_step at the price of the block test.  The state at
-    // the last test point (y, the carried phase factor, the steps since its seed) is kept; when a test finds a lane of the
+    // the last test point (y and the carried phase factor) is kept; when a test finds a lane of the
     // wave newly non-finite, the steps since then are REPLAYED on a copy with the reference's per-step test
     // (integrators.py:132-135).  The replay repeats the forward pass operation for operation (same chunks, same re-seeds,
     // same FMA sequence), so it reproduces this kernel's own trajectory bit for bit and the index it finds is exact.  Only
@@ -387,8 +391,8 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     // (the per-step test cost 9.9 of 310.6 instructions per step, profiles/r03_c2x_pmc.csv).
     constexpr bool REPLAY = FUSE && CHECK == CHECK_EXACT;
     T y_chk[REPLAY ? NC : 1], Er_chk[REPLAY ? NP : 1], Ei_chk[REPLAY ? NP : 1];
-    int i_chk = 0, ss_chk = RESYNC;
-    auto checkpoint = [&](const int step, const int since_seed) {
+    int i_chk = 0;
+    auto checkpoint = [&](const int step) {
         if constexpr (REPLAY) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) y_chk[c] = y[c];
@@ -398,10 +402,9 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
                 Ei_chk[p] = Ei[p];
             }
             i_chk = step;
-            ss_chk = since_seed;
         }
     };
-    auto exact_test = [&](const int i_now, const int since_seed) {   // at a test point: y is the state after step i_now - 1
+    auto exact_test = [&](const int i_now) {   // at a test point: y is the state after step i_now - 1
         if constexpr (REPLAY) {
             const bool newly_bad = bad < 0 && any_nonfinite<T, NC>(y);
             if (__builtin_amdgcn_ballot_w64(newly_bad) != 0) {
@@ -413,23 +416,20 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
                     er[p] = Er_chk[p];
                     ei[p] = Ei_chk[p];
                 }
-                int ii = i_chk, ss = ss_chk;
+                int ii = i_chk;
                 while (ii < i_now) {
-                    if (ss >= RESYNC) {
-                        seed_phase_on(ii, er, ei);
-                        ss = 0;
-                    }
-                    const int e = (i_now - ii > RESYNC / 2) ? ii + RESYNC / 2 : i_now;
+                    if (ii % RESYNC == 0) seed_phase_on(ii, er, ei);      // the forward pass seeds at the same steps
+                    const int to_seed = RESYNC - ii % RESYNC;
+                    const int e = (i_now - ii > to_seed) ? ii + to_seed : i_now;
 #pragma nounroll
                     for (int st = ii; st < e; ++st) {
                         rk4_step_on(yy, er, ei);
                         if (bad < 0 && any_nonfinite<T, NC>(yy)) bad = st;
                     }
-                    ss += e - ii;
                     ii = e;
                 }
             }
-            checkpoint(i_now, since_seed);
+            checkpoint(i_now);
         }
     };
 
@@ -474,18 +474,20 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     // ---- z-loop, event driven: the steps between two events (a saved row, a phase re-seed, the end) run in a
     // branch-free 2x-unrolled inner loop.  With one wave per SIMD (65 536 points fill the chip exactly once) every
     // taken branch is an exposed instruction refetch, so per-step `if`s cost ~6 % -- see DESIGN.md section 5.
-    constexpr int CHUNK = RESYNC / 2;
+    // Seeds fall on the ABSOLUTE grid i = 0, RESYNC, 2*RESYNC, ... whatever save_every is (the save_every == 1 loop above does
+    // the same), so the computed trajectory does not depend on which rows are saved -- as upstream, where the stride only
+    // selects rows (integrators.py:137-140): A[-1] at any stride equals the same row of the every-step run bit for bit.
     int i = 0;
-    int since_seed = RESYNC;           // forces the seed at i = 0
     int row = 0;
-    checkpoint(0, since_seed);
+    checkpoint(0);
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    int next_seed = 0;
     while (i < n_run) {
-        if (since_seed >= RESYNC) {    // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
+        if (i == next_seed) {          // wave-uniform: exact re-seed of the phase recurrence at z_i = i*h
             seed_phase(i);
-            since_seed = 0;
+            next_seed = (n_run - i > RESYNC) ? i + RESYNC : 0x7fffffff;   // no overflow near 2^31 steps
         }
-        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;   // no overflow near 2^31 steps
+        int end = n_run < next_seed ? n_run : next_seed;
         end = end < next_save ? end : next_save;
         const int m = end - i;
         int j = 0;
@@ -499,7 +501,6 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
             if (j < m) rk4_step(i + j);
         }
         i = end;
-        since_seed += m;
         if (i == next_save) {  // (i % save_every == 0), integrators.py:137 -- wave-uniform
             ++row;
             pe = fma_(y[4], y[4], y[5] * y[5]);
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
             if constexpr (CHECK == CHECK_BLOCK) {
                 if (bad < 0 && any_nonfinite<T, NC>(y)) bad = i - 1;
             }
-            exact_test(i, since_seed);
+            exact_test(i);
             if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {  // A[-1]: the last saved row, not necessarily z_max (R8)
 #pragma unroll
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK) PSA_SWEEP_KERNEL_ATTR rk4_sweep_kernel(
     if constexpr (CHECK == CHECK_BLOCK) {  // covers the unsaved tail
         if (bad < 0 && n_run > 0 && any_nonfinite<T, NC>(y)) bad = n_run - 1;
     }
-    if (n_run > i_chk) exact_test(n_run, since_seed);   // the unsaved tail (REPLAY only; compiled out otherwise)
+    if (n_run > i_chk) exact_test(n_run);   // the unsaved tail (REPLAY only; compiled out otherwise)
     write_summary();
 }
 

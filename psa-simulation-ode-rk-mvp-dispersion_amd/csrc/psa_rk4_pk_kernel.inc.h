@@ -7,7 +7,7 @@
 // instruction count advances twice the points (129.5 TFLOP/s measured with one wave per SIMD -- the shape of BASELINE
 // config 4's per-GPU shard -- and 140-147 with four or more).  Same algorithm and arithmetic as the scalar float32 kernel
 // (classic low-storage RK4 on the un-fused RHS with a compensated state update, phase factor re-seeded from a
-// float64-reduced sincos every <= 24 steps), so the two agree to rounding.
+// float64-reduced sincos every 16 steps), so the two agree to rounding.
 #pragma once
 #include "psa_rk4_kernel.inc.h"
 
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
     // SMALL running offset dl that collects the increments (rounded at ulp(dl) ~ 1e-4 ulp(y)); y = fl(yb + dl) is formed once
     // per step for the stage inputs, and every FOLD steps dl is folded into yb with its rounding residue kept (Fast2Sum).
     // 16 + 8 + 24/FOLD instructions per step and component pair against 40 for a Kahan update of y every step.
-    constexpr int FOLD = 16;
+    constexpr int FOLD = RESYNC;      // folded where the phase is re-seeded
     V yb[NC], dl[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -218,19 +218,19 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
         }
     }
 
-    constexpr int CHUNK = RESYNC / 2;
-    int i = 0, since_seed = RESYNC, row = 0, since_fold = 0;
+    // seeds (and the folds of the compensated state, FOLD == RESYNC) on the absolute grid i = 0, RESYNC, ...: the trajectory
+    // does not depend on save_every (see rk4_sweep_kernel)
+    static_assert(FOLD == RESYNC, "the state is folded where the phase is re-seeded");
+    int i = 0, row = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
+    int next_seed = 0;
     while (i < n_run) {
-        if (since_seed >= RESYNC) {
+        if (i == next_seed) {
             seed((double)i * hd, Er, Ei, tg);
-            since_seed = 0;
-        }
-        if (since_fold >= FOLD) {
             fold();
-            since_fold = 0;
+            next_seed = (n_run - i > RESYNC) ? i + RESYNC : 0x7fffffff;
         }
-        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
+        int end = n_run < next_seed ? n_run : next_seed;
         end = end < next_save ? end : next_save;
         const int m = end - i;
         int j = 0;
@@ -240,8 +240,6 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_pk_kernel(const SweepArgs<flo
         }
         if (j < m) rk4_step(i + j);
         i = end;
-        since_seed += m;
-        since_fold += m;
         if (i == next_save) {
             ++row;
             pe = fma_(y[4], y[4], y[5] * y[5]);

@@ -213,41 +213,37 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     // exchanges their partial sums), and the replay's own exchanges stay within the pair.
     constexpr bool REPLAY = CHECK == CHECK_EXACT;
     double y_chk[REPLAY ? NC : 1], Er_chk = 0.0, Ei_chk = 0.0;
-    int i_chk = 0, ss_chk = RESYNC;
-    auto checkpoint = [&](const int step, const int since_seed) {
+    int i_chk = 0;
+    auto checkpoint = [&](const int step) {
         if constexpr (REPLAY) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) y_chk[c] = y[c];
             Er_chk = Er;
             Ei_chk = Ei;
             i_chk = step;
-            ss_chk = since_seed;
         }
     };
-    auto exact_test = [&](const int i_now, const int since_seed) {
+    auto exact_test = [&](const int i_now) {
         if constexpr (REPLAY) {
             const bool newly_bad = bad < 0 && point_nonfinite();
             if (__builtin_amdgcn_ballot_w64(newly_bad) != 0) {
                 double yy[NC], er = Er_chk, ei = Ei_chk;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) yy[c] = y_chk[c];
-                int ii = i_chk, ss = ss_chk;
+                int ii = i_chk;
                 while (ii < i_now) {
-                    if (ss >= RESYNC) {
-                        seed_on(ii, er, ei);
-                        ss = 0;
-                    }
-                    const int e = (i_now - ii > RESYNC / 2) ? ii + RESYNC / 2 : i_now;
+                    if (ii % RESYNC == 0) seed_on(ii, er, ei);            // the forward pass seeds at the same steps
+                    const int to_seed = RESYNC - ii % RESYNC;
+                    const int e = (i_now - ii > to_seed) ? ii + to_seed : i_now;
 #pragma nounroll
                     for (int st = ii; st < e; ++st) {
                         rk4_step_on(yy, er, ei);
                         if (bad < 0 && nonfinite_on(yy)) bad = st;
                     }
-                    ss += e - ii;
                     ii = e;
                 }
             }
-            checkpoint(i_now, since_seed);
+            checkpoint(i_now);
         }
     };
 
@@ -334,16 +330,17 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
         }
     }
 
-    constexpr int CHUNK = RESYNC / 2;
-    int i = 0, since_seed = RESYNC, row = 0;
+    // seeds on the absolute grid i = 0, RESYNC, ...: the trajectory does not depend on save_every (see rk4_sweep_kernel)
+    int i = 0, row = 0;
     int next_save = (n_rows > 0) ? se : 0x7fffffff;
-    checkpoint(0, since_seed);
+    int next_seed = 0;
+    checkpoint(0);
     while (i < n_run) {
-        if (since_seed >= RESYNC) {
+        if (i == next_seed) {
             seed_on(i, Er, Ei);
-            since_seed = 0;
+            next_seed = (n_run - i > RESYNC) ? i + RESYNC : 0x7fffffff;
         }
-        int end = (n_run - i > CHUNK) ? i + CHUNK : n_run;
+        int end = n_run < next_seed ? n_run : next_seed;
         end = end < next_save ? end : next_save;
         const int m = end - i;
         int j = 0;
@@ -353,7 +350,6 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
         }
         if (j < m) rk4_step(i + j);
         i = end;
-        since_seed += m;
         if (i == next_save) {
             ++row;
             pe = fma_(y[SIG], y[SIG], y[SIG + 1] * y[SIG + 1]);
@@ -361,7 +357,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
             if constexpr (CHECK == CHECK_BLOCK) {
                 if (bad < 0 && point_nonfinite()) bad = i - 1;
             }
-            exact_test(i, since_seed);
+            exact_test(i);
             if constexpr (TRAJ) store_traj_row(row);
             if (row == n_rows) {
                 store_a_end();
@@ -374,7 +370,7 @@ __global__ void __launch_bounds__(BLOCK) rk4_sweep_split_kernel(const SweepArgs<
     if constexpr (CHECK == CHECK_BLOCK) {
         if (bad < 0 && n_run > 0 && point_nonfinite()) bad = n_run - 1;
     }
-    if (n_run > i_chk) exact_test(n_run, since_seed);   // the unsaved tail (CHECK_EXACT only)
+    if (n_run > i_chk) exact_test(n_run);   // the unsaved tail (CHECK_EXACT only)
     if (owns_signal) {
         A.p_end[idx] = pe;
         A.p_max[idx] = pm;

@@ -155,3 +155,29 @@ def test_padded_trajectory_leading_dimension(oracle):
             for k, i in enumerate(pick):
                 assert rel_err(tr[:, :, k, 0] + 1j * tr[:, :, k, 1], rows[i]) < tol, (N, flags, i)
             assert np.array_equal(got["a_end"], ds.result().a_end)
+
+
+@pytest.mark.parametrize("layout", ["f64_one", "f64_two", "f32_packed", "f32_scalar"])
+@pytest.mark.parametrize("nw", [4, 6])
+def test_the_computed_trajectory_does_not_depend_on_save_every(layout, nw):
+    """Upstream the stride only SELECTS rows (integrators.py:137-140): the arithmetic of step i is the same whatever is saved.
+    Here the phase recurrence is re-seeded (and the float32 state folded) on the absolute grid i = 0, 64, 128, ... (16 in
+    float32), not relative to saved rows, so the same holds bit for bit: row k of a run with stride s equals row k*s of the
+    every-step run, A[-1] is that run's row (n // s) * s, for strides around the seed grid and beyond the run -- in every lane
+    layout, and also for the summary-only kernels (no trajectory requested)."""
+    f32 = layout.startswith("f32")
+    flags = {"f64_one": nat.OPT_ONE_LANE, "f64_two": nat.OPT_SPLIT_POINT, "f32_packed": nat.OPT_F32_PACKED,
+             "f32_scalar": nat.OPT_F32_SCALAR}[layout]
+    N, n = 131, 333
+    db, db2, gam, al, a0 = _inputs(N, nw, 5 * nw + len(layout))
+    kw = dict(n_steps=n, z_max=33.3, gamma=gam, alpha=al, a0=a0, dbeta2=db2, dtype=np.float32 if f32 else np.float64,
+              extra_flags=flags)
+    every = nat.sweep_host(db, save_every=1, want_traj=True, **kw)
+    assert every["traj"].shape == (N, n + 1, nw) and (every["first_bad_step"] == -1).all()
+    for se in (2, 3, 7, 10, 16, 31, 64, 65, 100, 333, 1000):
+        got = nat.sweep_host(db, save_every=se, want_traj=True, **kw)
+        assert np.array_equal(got["traj"], every["traj"][:, ::se, :][:, :n // se + 1, :]), (layout, nw, se)
+        assert np.array_equal(got["a_end"], every["traj"][:, n // se * se, :]), (layout, nw, se)
+        summ = nat.sweep_host(db, save_every=se, want_traj=False, **kw)             # the non-trajectory instantiation
+        assert np.array_equal(summ["a_end"], got["a_end"]) and np.array_equal(summ["p_max"], got["p_max"]), (layout, nw, se)
+        assert np.array_equal(summ["p_end"], got["p_end"])

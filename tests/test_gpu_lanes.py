@@ -157,9 +157,9 @@ def test_exact_first_bad_step_comes_from_a_replay_of_the_failing_block(oracle, l
     stay finite.  Three bars:
       * every se: the block-mode run of the same sweep must name the block the exact index lies in, and finite points must be
         bit-identical in both modes (the forward pass is the same code);
-      * se a multiple of 64: chunks and re-seeds then fall where the save_every = 1 trajectory loop puts them, so the forward
-        pass is bit-identical to that run, whose per-row test IS a per-step test: the replayed index must EQUAL it, for
-        every failing point, chaotic or not;
+      * every se: the phase re-seeds sit on the absolute step grid, so the forward pass is bit-identical to the
+        save_every = 1 trajectory run, whose per-row test IS a per-step test: the replayed index must EQUAL it, for every
+        failing point, chaotic or not;
       * against the oracle: equal for the points whose blow-up is abrupt; the late ones (|alpha| ~ 1: hundreds of radians of
         nonlinear phase before they fail) are chaotic -- implementations 1e-12 apart fail at different steps -- and only
         have to fail."""
@@ -185,10 +185,9 @@ def test_exact_first_bad_step_comes_from_a_replay_of_the_failing_block(oracle, l
     ok = ~failed
     assert rel_err(got["a_end"][ok], ref["a_end"][ok]) < RTOL_F64 and np.array_equal(got["a_end"][ok], blk["a_end"][ok])
     assert np.array_equal(got["p_max"][ok], blk["p_max"][ok])
-    if se % 64 == 0:
-        every = nat.sweep_host(db, save_every=1, exact_step=True, want_traj=True, **kw)   # per-row == per-step test, no replay
-        assert np.array_equal(got["first_bad_step"], every["first_bad_step"])
-        if last_saved:
-            assert np.array_equal(got["a_end"][ok], every["traj"][ok, last_saved, :])
+    every = nat.sweep_host(db, save_every=1, exact_step=True, want_traj=True, **kw)   # per-row == per-step test, no replay
+    assert np.array_equal(got["first_bad_step"], every["first_bad_step"])
+    if last_saved:
+        assert np.array_equal(got["a_end"][ok], every["traj"][ok, last_saved, :])
     abrupt = failed & (al < -3.0)
     assert abrupt.sum() >= 30 and np.array_equal(got["first_bad_step"][abrupt], want[abrupt])

@@ -1,3 +1,4 @@
+# A/B against a build of an EARLIER commit: make it with  git worktree add /tmp/prev <commit> && make -C /tmp/prev/psa-*/csrc && cp /tmp/prev/psa-*/libpsa_hip.so ab/libpsa_hip_prev.so
 # aligned build (HEAD) vs the previous commit's build (ab/libpsa_hip_prev.so: blocks where they fell) on one box
 for v in prev cur; do
   if [ $v = cur ]; then unset PSA_HIP_LIB; else export PSA_HIP_LIB=$PWD/ab/libpsa_hip_$v.so; fi

@@ -1,3 +1,4 @@
+# A/B against a build of an EARLIER commit: make it with  git worktree add /tmp/prev <commit> && make -C /tmp/prev/psa-*/csrc && cp /tmp/prev/psa-*/libpsa_hip.so ab/libpsa_hip_prev.so
 export TMPDIR=/tmp
 O=gpurun_out/r3r; rm -rf $O; mkdir -p $O
 for v in prev cur; do

@@ -146,7 +146,8 @@ int psa_rk4_sweep_f32(int device, int n_waves, int64_t n_points, int64_t n_steps
  * Device layout is SoA so that every wave instruction is a contiguous 512-B (f64) access:
  *   d_a0_soa    [2*n_waves][N] (or [2*n_waves][1] with PSA_BCAST_A0): row 2j = Re A_j, 2j+1 = Im A_j
  *   d_a_end_soa [2*n_waves][N]
- *   d_traj_soa  [n_saved][n_waves][N][2] ((re, im) pairs: 16-B stores, 1 KiB per wave instruction) or NULL
+ *   d_traj_soa  [n_saved][n_waves][ld][2] ((re, im) pairs: 16-B stores, 1 KiB per wave instruction) or NULL;
+ *               ld = N, or psa_traj_ld(N, sizeof(element)) with PSA_OPT_TRAJ_LD (rows padded off a 2 MiB stride)
  * `stream` is a hipStream_t (NULL = default stream).  No allocation, no synchronisation: safe to capture
  * into a hipGraph.  This is what bench.py times and what the multi-GPU path calls per rank.
  */

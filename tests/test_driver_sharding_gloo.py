@@ -119,7 +119,15 @@ def _driver_calls():
                                                p_in=[0.3, 0.25, 1e-6, 1e-6, 2e-6, 5e-7], dispersion=d13, dbeta_producer="host")
         return dict(gain=out["gain"], a_end=out["a_end"], bad=out["first_bad_step"])
 
-    calls.update(g2=c_g2, g3=c_g3, g13_sym=c_g13(None),
+    def c_tiny():
+        """Fewer points than ranks (world 3): one rank's block is empty -- it still takes part in the exchange."""
+        x, gain, db = scan_mismtach.plot_max_gain_and_dbeta_vs_lambda_signal(
+            cfg=config.custom_simulation_config(z_max=50.0, dz=0.2), lambda_p1_m=float(g2["lambda_p1"]),
+            lambda_p2_m=float(g2["lambda_p2"]), lambda_signal_m=g2["lambda3"][13:15], gamma=float(g2["gamma"]),
+            alpha=float(g2["alpha"]), p_in=g2["p_in"], dispersion=_disp(g2), show=False, show_progress=False)
+        return dict(gain=gain, dbeta=db)
+
+    calls.update(g2=c_g2, g3=c_g3, tiny=c_tiny, g13_sym=c_g13(None),
                  g13_gen=c_g13(PhaseMatchingConfig(method=PhaseMatchingMethod.GENERAL_TAYLOR, max_order=4)),
                  holes=c_holes, scan=c_scan, six=c_six)
     return calls
@@ -141,14 +149,16 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sizes.clear()
-        shard = {k: f() for k, f in calls.items()}
-        flat = None
+        shard, per_call = {}, []
+        for k, f in calls.items():
+            sizes.clear()
+            shard[k] = f()
+            per_call.append(sum(sizes))          # points this rank integrated for this driver call (0: an empty block)
         flat = {f"{k}.{name}": v for k, d in shard.items() for name, v in d.items()}
         if whole is not None:
             flat.update({f"whole.{k}.{name}": v for k, d in whole.items() for name, v in d.items()})
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **flat)
-        np.save(os.path.join(out_dir, f"sizes{rank}.npy"), np.array(sizes))
+        np.save(os.path.join(out_dir, f"sizes{rank}.npy"), np.array(per_call))
     finally:
         dist.destroy_process_group()
 
@@ -158,11 +168,13 @@ def test_drivers_shard_over_the_process_group_and_every_rank_gets_the_whole_swee
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     r0 = ranks[0]
-    # each rank integrated only its block: g2 30 points, g3 25, g13 36 (twice), holes 12 of 14, scan 41, six 35
-    totals = [30, 25, 36, 36, 12, 41, 35]
+    # each rank integrated only its block: g2 30 points, g3 25, tiny 2, g13 36 (twice), holes 12 of 14, scan 41, six 35
+    totals = [30, 25, 2, 36, 36, 12, 41, 35]
     per_rank = np.stack([np.load(tmp_path / f"sizes{r}.npy") for r in range(world)])
     assert per_rank.shape == (world, len(totals)) and list(per_rank.sum(axis=0)) == totals
     assert (per_rank.max(axis=0) - per_rank.min(axis=0) <= 2).all()
+    if world == 3:
+        assert sorted(per_rank[:, 2]) == [0, 1, 1]                  # "tiny": two points, three ranks
     keys = [k for k in r0.files if not k.startswith("whole.")]
     assert len(keys) >= 20
     for k in keys:

@@ -35,10 +35,11 @@ def single_simulation():
     om, sp, disp = dispersion_at_pump_centre(1550e-9, 1560e-9, 1555e-9, 0.02)
     print(describe_plan(om))
     p_in = np.array([0.5, 0.5, 1e-5, 1e-5])
-    t = time.perf_counter()
-    z, A = run_single_simulation(custom_simulation_config(z_max=1000.0, dz=0.1), gamma=GAMMA, alpha=alpha_of(0.9), omega=om,
-                                 p_in=p_in, phase_in=np.zeros(4), dispersion=disp, phase_matching_cfg=PM)
-    dt = time.perf_counter() - t
+    for _ in range(2):          # the first call of a process also loads the library and the HIP module (~0.2 s): time the second
+        t = time.perf_counter()
+        z, A = run_single_simulation(custom_simulation_config(z_max=1000.0, dz=0.1), gamma=GAMMA, alpha=alpha_of(0.9), omega=om,
+                                     p_in=p_in, phase_in=np.zeros(4), dispersion=disp, phase_matching_cfg=PM)
+        dt = time.perf_counter() - t
     P_out = np.abs(A[-1]) ** 2
     print(f"z_end = {z[-1]:.3f} m, rows = {len(z)}, P_out = {P_out}")
     print(f"signal gain = {10 * np.log10(P_out[2] / p_in[2]):.6f} dB   (reference: 45.292444 dB)")

@@ -51,7 +51,7 @@ extern "C" {
 #define PSA_E_DBETA2     -8   /* n_waves == 6 needs dbeta2; n_waves == 4 forbids it  */
 #define PSA_E_TOO_LARGE  -9   /* trajectory does not fit (int64 / device memory), or n_points exceeds the launch grid */
 #define PSA_E_DBETA_MODEL -10 /* dbeta producer: unknown method, bad even_orders / max_order / beta count  */
-#define PSA_E_FLAGS      -11  /* two options that exclude each other (SPLIT_POINT + ONE_LANE, F32_SCALAR + F32_PACKED) */
+#define PSA_E_FLAGS      -11  /* options that exclude each other (two of SPLIT_POINT / ONE_LANE / QUAD_POINT, F32_SCALAR + F32_PACKED, QUAD with 6 waves) */
 
 /* The most points one launch takes: a launch has at most 2^32 - 1 threads in x and the two-lane float64 layout uses two
  * per point.  (2^31 - 256 float64 records are 189 GB: a 288 GB MI355X holds them, so the limit is stated, not theoretical.) */
@@ -84,6 +84,11 @@ extern "C" {
                                             neighbouring lanes, partial sums exchanged by DPP): halves the sequential
                                             instruction stream per lane.  Default: chosen automatically when the sweep is
                                             smaller than the chip (2*N lanes still get one SIMD per wave: N <= 32 768).   */
+#define PSA_OPT_QUAD_POINT   (1u << 18)  /* float64, n_waves == 4 only: force FOUR lanes per sweep point (one wave of the model
+                                            per lane, sums and products exchanged by DPP within the quad): ~155
+                                            instructions per step and lane.  Default: chosen automatically while 4*N
+                                            lanes still get one SIMD per wave (N <= 16 384) -- the reference's own
+                                            scenarios (1, 30, 100 points).                                          */
 #define PSA_OPT_ONE_LANE     (1u << 16)  /* float64 only: never split a point over two lanes                              */
 #define PSA_OPT_TRAJ_LD      (1u << 17)  /* `_dev` entry points: the trajectory buffer is [n_saved][n_waves][ld][2] with the
                                             leading dimension ld = psa_traj_ld(n_points, sizeof(element)) >= n_points

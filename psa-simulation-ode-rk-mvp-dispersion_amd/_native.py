@@ -37,6 +37,7 @@ OPT_LOSSLESS = 1 << 14
 OPT_SPLIT_POINT = 1 << 15
 OPT_ONE_LANE = 1 << 16
 OPT_TRAJ_LD = 1 << 17
+OPT_QUAD_POINT = 1 << 18
 MAX_POINTS = 2**31 - 256          # PSA_MAX_POINTS: the most points one launch takes
 
 # every symbol the header declares, with (restype, argtypes)

@@ -66,8 +66,13 @@ int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max
     if (save_every <= 0) return fail(PSA_E_SAVE_EVERY, "save_every must be a positive integer");
     if (n_waves == 6 && !dbeta2 && n_points > 0) return fail(PSA_E_DBETA2, "n_waves == 6 requires dbeta2");
     if (n_waves == 4 && dbeta2) return fail(PSA_E_DBETA2, "dbeta2 must be NULL for n_waves == 4");
-    if ((flags & PSA_OPT_SPLIT_POINT) && (flags & PSA_OPT_ONE_LANE))
-        return fail(PSA_E_FLAGS, "PSA_OPT_SPLIT_POINT and PSA_OPT_ONE_LANE exclude each other");
+    {
+        const int layouts = !!(flags & PSA_OPT_SPLIT_POINT) + !!(flags & PSA_OPT_ONE_LANE) + !!(flags & PSA_OPT_QUAD_POINT);
+        if (layouts > 1)
+            return fail(PSA_E_FLAGS, "PSA_OPT_SPLIT_POINT, PSA_OPT_ONE_LANE and PSA_OPT_QUAD_POINT exclude each other");
+        if ((flags & PSA_OPT_QUAD_POINT) && n_waves != 4)
+            return fail(PSA_E_FLAGS, "PSA_OPT_QUAD_POINT (four lanes per point) exists for the 4-wave model only");
+    }
     if ((flags & PSA_OPT_F32_SCALAR) && (flags & PSA_OPT_F32_PACKED))
         return fail(PSA_E_FLAGS, "PSA_OPT_F32_SCALAR and PSA_OPT_F32_PACKED exclude each other");
     if (n_points > 0 && (!dbeta || !gamma || !alpha || !a0 || !a_end || !p_end || !p_max || !first_bad))
@@ -79,7 +84,7 @@ int validate_common(int n_waves, int64_t n_points, int64_t n_steps, double z_max
             return fail(PSA_E_TOO_LARGE, "a trajectory launch takes at most %llu points", (1ull << 31) / pair - 1);
         // the two-lane layout folds the lane's wave offset into that 32-bit offset
         const unsigned long long ld = (flags & PSA_OPT_TRAJ_LD) ? (unsigned long long)traj_ld_of(n_points, elem_size) : (unsigned long long)n_points;
-        if ((flags & PSA_OPT_SPLIT_POINT) && ld * n_waves * pair >= (1ull << 32))
+        if ((flags & (PSA_OPT_SPLIT_POINT | PSA_OPT_QUAD_POINT)) && ld * n_waves * pair >= (1ull << 32))
             return fail(PSA_E_TOO_LARGE, "a two-lane trajectory launch takes at most %llu points",
                         (1ull << 32) / (n_waves * pair) - 1);
     }
@@ -123,7 +128,7 @@ template <typename T> struct Launch;
 template <> struct Launch<double> {
     static hipError_t sweep(hipStream_t s, int nw, int chk, bool lds, int blk, uint32_t flags,
                             const psa::SweepArgs<double> &a) {
-        const int split = (flags & PSA_OPT_SPLIT_POINT) ? 1 : ((flags & PSA_OPT_ONE_LANE) ? 0 : -1);
+        const int split = (flags & PSA_OPT_QUAD_POINT) ? 2 : ((flags & PSA_OPT_SPLIT_POINT) ? 1 : ((flags & PSA_OPT_ONE_LANE) ? 0 : -1));
         return psa::launch_sweep_f64(s, nw, chk, lds, blk, (flags & PSA_OPT_LOSSLESS) != 0, split, a);
     }
     static hipError_t a2s(hipStream_t s, const double *a, double *b, long long n, int nc) { return psa::launch_aos_to_soa_f64(s, a, b, n, nc); }

@@ -32,7 +32,7 @@ enum CheckMode : int { CHECK_NONE = 0, CHECK_BLOCK = 1, CHECK_EXACT = 2 };
 
 // launchers (defined in psa_rk4_f64.hip / psa_rk4_f32.hip)
 // lossless: the caller promises alpha == 0 for every point -> instantiation without the loss links
-// split: 1 two lanes per point (float64 only), 0 one lane per point, -1 auto (see psa_rk4_f64.hip)
+// split: 1 two lanes per point, 2 four lanes per point (4 waves) -- float64 only --, 0 one lane per point, -1 auto (psa_rk4_f64.hip)
 hipError_t launch_sweep_f64(hipStream_t s, int n_waves, int check, bool lds, int block, bool lossless, int split,
                             const SweepArgs<double> &a);
 hipError_t launch_sweep_f32(hipStream_t s, int n_waves, int check, bool lds, int block, int pack, bool lossless,

@@ -38,7 +38,7 @@ def test_flag_values_match_the_header():
                       ("PSA_OPT_BLOCK64", nat.OPT_BLOCK64), ("PSA_OPT_F32_SCALAR", nat.OPT_F32_SCALAR),
                       ("PSA_OPT_F32_PACKED", nat.OPT_F32_PACKED), ("PSA_OPT_LOSSLESS", nat.OPT_LOSSLESS),
                       ("PSA_OPT_SPLIT_POINT", nat.OPT_SPLIT_POINT), ("PSA_OPT_ONE_LANE", nat.OPT_ONE_LANE),
-                      ("PSA_OPT_TRAJ_LD", nat.OPT_TRAJ_LD)):
+                      ("PSA_OPT_TRAJ_LD", nat.OPT_TRAJ_LD), ("PSA_OPT_QUAD_POINT", nat.OPT_QUAD_POINT)):
         m = re.search(rf"#define\s+{name}\s+\(1u\s*<<\s*(\d+)\)", src)
         assert m and (1 << int(m.group(1))) == val, name
 
@@ -220,6 +220,8 @@ def test_trajectory_launch_limits_and_contradictory_flags():
     assert L.psa_rk4_sweep_f32_dev(None, 4, 2**28, 10, 1.0, 1, p, None, p, p, p, 0, p, p, p, p, p) == -9
     assert f64(2**26, nat.OPT_SPLIT_POINT) == -9 and f64(2**26 // 6 * 4 + 8, nat.OPT_SPLIT_POINT, nw=6) == -9
     assert f64(8, nat.OPT_SPLIT_POINT | nat.OPT_ONE_LANE, traj=None) == -11
+    assert f64(8, nat.OPT_QUAD_POINT | nat.OPT_ONE_LANE, traj=None) == -11 and f64(8, nat.OPT_QUAD_POINT, nw=6, traj=None) == -11
+    assert f64(2**26, nat.OPT_QUAD_POINT) == -9
     assert L.psa_rk4_sweep_f32_dev(None, 4, 8, 10, 1.0, 1, p, None, p, p, p, nat.OPT_F32_SCALAR | nat.OPT_F32_PACKED,
                                    p, p, p, p, None) == -11
     assert b"exclude" in L.psa_last_error()

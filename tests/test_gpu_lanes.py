@@ -14,7 +14,8 @@ from conftest import RTOL_F64, rel_err
 pytestmark = pytest.mark.gpu
 
 LANES = [pytest.param(nat.OPT_ONE_LANE, id="one-lane"), pytest.param(nat.OPT_SPLIT_POINT, id="two-lanes"),
-         pytest.param(nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, id="two-lanes-wg64")]
+         pytest.param(nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, id="two-lanes-wg64"),
+         pytest.param(nat.OPT_QUAD_POINT, id="four-lanes"), pytest.param(nat.OPT_QUAD_POINT | nat.OPT_BLOCK64, id="four-lanes-wg64")]
 P_IN = np.array([0.5, 0.5, 1e-5, 1e-5])
 A0 = np.sqrt(P_IN).astype(complex)
 A06 = np.concatenate([A0, np.sqrt([2e-5, 1e-6])])
@@ -147,7 +148,7 @@ def test_automatic_layout_choice_is_invisible_in_the_results(oracle):
 
 
 @pytest.mark.parametrize("se", [7, 50, 64, 192, 1024])
-@pytest.mark.parametrize("lanes", [nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT])
+@pytest.mark.parametrize("lanes", [nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_QUAD_POINT])
 def test_exact_first_bad_step_comes_from_a_replay_of_the_failing_block(oracle, lanes, se):
     """PSA_OPT_EXACT_STEP in float64 costs nothing in the steady-state loop: the forward pass tests once per saved row and a
     wave with a newly failing point REPLAYS the steps since the previous test with the reference's per-step test
@@ -191,3 +192,46 @@ def test_exact_first_bad_step_comes_from_a_replay_of_the_failing_block(oracle, l
         assert np.array_equal(got["a_end"][ok], every["traj"][ok, last_saved, :])
     abrupt = failed & (al < -3.0)
     assert abrupt.sum() >= 30 and np.array_equal(got["first_bad_step"][abrupt], want[abrupt])
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 63, 64, 65, 1000, 16_384, 16_385])
+def test_four_lane_layout_matches_the_others(oracle, N):
+    """Four lanes per point (one wave of the 4-wave model per lane, PSA_OPT_QUAD_POINT): sizes around the 16-point wave
+    boundary and the largest sweep that takes this layout by itself; per-point gamma / alpha / amplitudes with phases, a
+    lossless run, saved rows, every check mode -- against the oracle (1e-9), the two-lane layout (1e-11: the layouts differ
+    by which factor of A_u*A_v is the FMA's exact one) and, for N <= 16 384, the library's own choice (bit for bit)."""
+    rng = np.random.default_rng(N)
+    db = rng.uniform(-0.08, 0.08, N)
+    gam, al = rng.uniform(5e-3, 2e-2, N), rng.uniform(0.0, 3e-4, N)
+    a0 = np.sqrt(rng.uniform([0.2, 0.2, 1e-6, 1e-6], [0.8, 0.8, 1e-3, 1e-3], (N, 4))) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, 4)))
+    n, se = (600, 7) if N <= 1000 else (200, 10)
+    small = N <= 1000
+    kw = dict(n_steps=n, z_max=0.1 * n, save_every=se, gamma=gam, alpha=al, a0=a0, want_traj=small)
+    pick = np.arange(N) if small else rng.choice(N, 64, replace=False)
+    ref = oracle.sweep(db[pick], z_max=0.1 * n, n=n, save_every=se, gamma=gam[pick], alpha=al[pick], a0=a0[pick])
+    two = nat.sweep_host(db, extra_flags=nat.OPT_SPLIT_POINT, **kw)
+    for flags in (nat.OPT_QUAD_POINT, nat.OPT_QUAD_POINT | nat.OPT_BLOCK64):
+        for check in (dict(check_nan=True, exact_step=True), dict(check_nan=True, exact_step=False), dict(check_nan=False)):
+            four = nat.sweep_host(db, extra_flags=flags, **kw, **check)
+            assert rel_err(four["a_end"][pick], ref["a_end"]) < RTOL_F64 and rel_err(four["p_max"][pick], ref["p_max"]) < RTOL_F64
+            assert rel_err(four["p_end"][pick], ref["p_end"]) < RTOL_F64 and (four["first_bad_step"] == -1).all()
+            assert rel_err(four["a_end"], two["a_end"]) < 1e-11
+            if small:
+                assert rel_err(four["traj"], two["traj"]) < 1e-11 and np.array_equal(four["traj"][:, -1, :], four["a_end"])
+    auto = nat.sweep_host(db, **kw)
+    forced = nat.sweep_host(db, extra_flags=(nat.OPT_QUAD_POINT if N <= 16_384 else nat.OPT_SPLIT_POINT), **kw)
+    assert np.array_equal(auto["a_end"], forced["a_end"]) and np.array_equal(auto["p_max"], forced["p_max"])
+    lossless = nat.sweep_host(db, extra_flags=nat.OPT_QUAD_POINT, **{**kw, "alpha": 0.0, "want_traj": False})
+    power = (np.abs(lossless["a_end"]) ** 2).sum(1)
+    np.testing.assert_allclose(power, (np.abs(a0) ** 2).sum(1), rtol=1e-11)
+
+
+def test_four_lanes_are_for_the_four_wave_model_only():
+    with pytest.raises(nat.PsaNativeError) as e:
+        nat.sweep_host(np.zeros(4), dbeta2=np.zeros(4), n_steps=10, z_max=1.0, save_every=1, gamma=0.01, alpha=0.0, a0=A06,
+                       extra_flags=nat.OPT_QUAD_POINT)
+    assert e.value.code == -11
+    with pytest.raises(nat.PsaNativeError) as e:
+        nat.sweep_host(np.zeros(4), n_steps=10, z_max=1.0, save_every=1, gamma=0.01, alpha=0.0, a0=A0,
+                       extra_flags=nat.OPT_QUAD_POINT | nat.OPT_SPLIT_POINT)
+    assert e.value.code == -11

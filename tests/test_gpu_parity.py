@@ -36,7 +36,8 @@ def test_sweep_matches_oracle_on_ragged_sizes(oracle, N, n, se):
     db = rng.uniform(-0.1, 0.1, N)
     ref = oracle.sweep(db, z_max=100.0, n=n, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0)
     # one lane per point (256- and 64-thread workgroups), two lanes per point, and the library's own choice
-    for flags in (nat.OPT_ONE_LANE, nat.OPT_ONE_LANE | nat.OPT_BLOCK64, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, 0):
+    for flags in (nat.OPT_ONE_LANE, nat.OPT_ONE_LANE | nat.OPT_BLOCK64, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64,
+                  nat.OPT_QUAD_POINT, nat.OPT_QUAD_POINT | nat.OPT_BLOCK64, 0):
         got = nat.sweep_host(db, n_steps=n, z_max=100.0, save_every=se, gamma=0.0115, alpha=1.15e-4, a0=A0,
                              check_nan=True, exact_step=True, extra_flags=flags)
         assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
@@ -57,7 +58,7 @@ def test_per_point_gamma_alpha_a0_robustness_draw(oracle):
                   10 ** rng.uniform(-7, -4, N)], 1)
     a0 = np.sqrt(P) * np.exp(1j * rng.uniform(-np.pi, np.pi, (N, 4)))
     ref = oracle.sweep(db, z_max=400.0, n=4000, save_every=10, gamma=gamma, alpha=alpha, a0=a0)
-    for lanes in (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT):
+    for lanes in (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_QUAD_POINT):
         got = nat.sweep_host(db, n_steps=4000, z_max=400.0, save_every=10, gamma=gamma, alpha=alpha, a0=a0, extra_flags=lanes)
         assert rel_err(got["a_end"], ref["a_end"]) < RTOL_F64
         assert rel_err(got["p_max"], ref["p_max"]) < RTOL_F64

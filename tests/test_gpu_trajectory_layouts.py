@@ -71,7 +71,7 @@ def test_two_lane_float64_trajectories(oracle, nw, N, n, se):
         assert rel_err(two["traj"][i], A) < RTOL_F64
 
 
-@pytest.mark.parametrize("layout", ["f64_one", "f64_two", "f32_packed", "f32_scalar"])
+@pytest.mark.parametrize("layout", ["f64_one", "f64_two", "f64_four", "f32_packed", "f32_scalar"])
 def test_failure_inside_a_save_every_1_trajectory(layout, oracle):
     """A point that blows up while every step is saved: first_bad_step is the reference's index in exact mode (and the same
     in block mode, where a block is one step), rows after it are non-finite, p_max is NaN -- neighbours (the other half of a
@@ -82,8 +82,8 @@ def test_failure_inside_a_save_every_1_trajectory(layout, oracle):
     gam[4] = 3.0e4                                  # overflows within a few steps in either precision
     a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
     f32 = layout.startswith("f32")
-    flags = {"f64_one": nat.OPT_ONE_LANE, "f64_two": nat.OPT_SPLIT_POINT, "f32_packed": nat.OPT_F32_PACKED,
-             "f32_scalar": nat.OPT_F32_SCALAR}[layout]
+    flags = {"f64_one": nat.OPT_ONE_LANE, "f64_two": nat.OPT_SPLIT_POINT, "f64_four": nat.OPT_QUAD_POINT,
+             "f32_packed": nat.OPT_F32_PACKED, "f32_scalar": nat.OPT_F32_SCALAR}[layout]
     ref = oracle.sweep(db, z_max=4.0, n=n, save_every=1, gamma=gam, alpha=1e-4, a0=a0)
     for exact in (True, False):
         got = nat.sweep_host(db, n_steps=n, z_max=4.0, save_every=1, gamma=gam, alpha=1e-4, a0=a0, want_traj=True,
@@ -134,7 +134,7 @@ def test_padded_trajectory_leading_dimension(oracle):
     assert nat.traj_ld(262_144) == 262_144 + 272 and nat.traj_ld(131_072, np.float32) == 131_072
     a0 = np.sqrt([0.5, 0.5, 1e-5, 1e-5]).astype(complex)
     n = 5
-    for N, dtype, layouts, tol in ((131_072, np.float64, (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT), RTOL_F64),
+    for N, dtype, layouts, tol in ((131_072, np.float64, (nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_QUAD_POINT), RTOL_F64),
                                   (262_144, np.float32, (nat.OPT_F32_PACKED, nat.OPT_F32_SCALAR), RTOL_F32)):
         db = np.linspace(-0.05, 0.05, N).astype(dtype)
         pick = [0, 1, 63, 64, N // 2 - 1, N // 2, N - 2, N - 1]
@@ -157,8 +157,8 @@ def test_padded_trajectory_leading_dimension(oracle):
             assert np.array_equal(got["a_end"], ds.result().a_end)
 
 
-@pytest.mark.parametrize("layout", ["f64_one", "f64_two", "f32_packed", "f32_scalar"])
-@pytest.mark.parametrize("nw", [4, 6])
+@pytest.mark.parametrize("layout,nw", [(lay, nw) for lay in ("f64_one", "f64_two", "f32_packed", "f32_scalar") for nw in (4, 6)]
+                         + [("f64_four", 4)])
 def test_the_computed_trajectory_does_not_depend_on_save_every(layout, nw):
     """Upstream the stride only SELECTS rows (integrators.py:137-140): the arithmetic of step i is the same whatever is saved.
     Here the phase recurrence is re-seeded (and the float32 state folded) on the absolute grid i = 0, 64, 128, ... (16 in
@@ -166,8 +166,8 @@ def test_the_computed_trajectory_does_not_depend_on_save_every(layout, nw):
     every-step run, A[-1] is that run's row (n // s) * s, for strides around the seed grid and beyond the run -- in every lane
     layout, and also for the summary-only kernels (no trajectory requested)."""
     f32 = layout.startswith("f32")
-    flags = {"f64_one": nat.OPT_ONE_LANE, "f64_two": nat.OPT_SPLIT_POINT, "f32_packed": nat.OPT_F32_PACKED,
-             "f32_scalar": nat.OPT_F32_SCALAR}[layout]
+    flags = {"f64_one": nat.OPT_ONE_LANE, "f64_two": nat.OPT_SPLIT_POINT, "f64_four": nat.OPT_QUAD_POINT,
+             "f32_packed": nat.OPT_F32_PACKED, "f32_scalar": nat.OPT_F32_SCALAR}[layout]
     N, n = 131, 333
     db, db2, gam, al, a0 = _inputs(N, nw, 5 * nw + len(layout))
     kw = dict(n_steps=n, z_max=33.3, gamma=gam, alpha=al, a0=a0, dbeta2=db2, dtype=np.float32 if f32 else np.float64,

@@ -48,7 +48,8 @@ while time.time() - t0 < budget and not (stop_at and case >= stop_at):
     alpha = rng.uniform(0, 3e-4, N) if rng.integers(0, 2) else float(rng.choice([0.0, 1.15e-4]))
     amp = np.sqrt(rng.uniform(1e-6, 0.8, (N, nw))) * np.exp(1j * rng.uniform(-3.1, 3.1, (N, nw)))
     a0 = amp if rng.integers(0, 2) else amp[0]
-    flags = int(rng.choice([0, nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, nat.OPT_BLOCK64]))
+    flags = int(rng.choice([0, nat.OPT_ONE_LANE, nat.OPT_SPLIT_POINT, nat.OPT_SPLIT_POINT | nat.OPT_BLOCK64, nat.OPT_BLOCK64]
+                           + ([nat.OPT_QUAD_POINT, nat.OPT_QUAD_POINT | nat.OPT_BLOCK64] if nw == 4 else [])))
     if f32:
         flags = int(rng.choice([0, nat.OPT_F32_SCALAR, nat.OPT_F32_PACKED]))
         db, db2 = db.astype(np.float32), (None if db2 is None else db2.astype(np.float32))
@@ -88,7 +89,7 @@ while time.time() - t0 < budget and not (stop_at and case >= stop_at):
         g_i = gamma[i] if np.ndim(gamma) else gamma
         print(f"   gamma of that point {g_i}, nonlinear phase gamma*P*L ~ {g_i * (np.abs(ref['a_end'][i]) ** 2).sum() * L:.1f} rad", flush=True)
         if not f32:
-            for nm, fl in (("one lane", nat.OPT_ONE_LANE), ("two lanes", nat.OPT_SPLIT_POINT)):
+            for nm, fl in (("one lane", nat.OPT_ONE_LANE), ("two lanes", nat.OPT_SPLIT_POINT)) + ((("four lanes", nat.OPT_QUAD_POINT),) if nw == 4 else ()):
                 alt = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2,
                                      check_nan=check, exact_step=exact, extra_flags=fl)
                 print(f"   {nm}: a_end[{i}] vs oracle {np.abs(alt['a_end'][i] - ref['a_end'][i]).max():.3e}, vs first run {np.abs(alt['a_end'][i] - got['a_end'][i]).max():.3e}", flush=True)

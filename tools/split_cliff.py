@@ -33,11 +33,13 @@ def run(nw, n, flags):
 
 
 print(f"# {n_steps} z-steps, float64, kernel ms (best of 3); model = relative cost, lower wins; auto = the library's choice")
-print(f"{'waves':>5} {'N':>8} {'one lane':>9} {'two lanes':>9} {'auto':>8} {'auto picks':>10} {'model 1':>8} {'model 2':>8} {'model picks':>11} {'best':>9}")
+print(f"{'waves':>5} {'N':>8} {'one lane':>9} {'two lanes':>9} {'auto':>8} {'auto picks':>10} {'model 1':>8} {'model 2':>8} {'model picks':>11} {'best':>9} {'four lanes':>10}")
 for nw in (4, 6):
-    for n in (16_384, 32_768, 32_769, 40_000, 49_152, 65_536, 65_537, 70_000, 81_920, 98_304, 98_305, 114_688, 131_072, 163_840, 262_144):
+    for n in (1, 100, 4_096, 16_384, 16_385, 32_768, 32_769, 40_000, 49_152, 65_536, 65_537, 70_000, 81_920, 98_304, 98_305, 114_688, 131_072, 163_840, 262_144):
         t1, t2, ta = run(nw, n, nat.OPT_ONE_LANE), run(nw, n, nat.OPT_SPLIT_POINT), run(nw, n, 0)
         m1, m2 = model(nw, n)
-        picks = "two" if abs(ta - t2) < abs(ta - t1) else "one"
+        t4 = run(nw, n, nat.OPT_QUAD_POINT) if (nw == 4 and n <= 32_768) else float("nan")
+        cand = {"one": t1, "two": t2, **({"four": t4} if t4 == t4 else {})}
+        picks = min(cand, key=lambda k: abs(ta - cand[k]))
         print(f"{nw:>5} {n:>8} {t1:>9.2f} {t2:>9.2f} {ta:>8.2f} {picks:>10} {m1:>8.0f} {m2:>8.0f} {'two' if m2 < m1 else 'one':>11} "
-              f"{'two' if t2 < t1 else 'one':>9}", flush=True)
+              f"{min(cand, key=cand.get):>9} {t4:>10.2f}", flush=True)

@@ -17,12 +17,14 @@ assembled once and the sizes are read back from the disassembly.
 
 Usage: align_encodings.py in.s out.s [--mcpu gfx950] [--quiet]
 """
+import os
 import re
 import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin/"
+LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin").rstrip("/") + "/"
+TMP = tempfile.TemporaryDirectory(prefix="psa_align_")      # removed when the script exits
 ENC = re.compile(r"// [0-9A-Fa-f]{12}: ((?:[0-9A-Fa-f]{8}\b ?)+)")      # the encoding column of llvm-objdump -d
 MIN_RUN = 3          # an s_nop is only worth its issue slot in front of this many 8-byte instructions
 
@@ -50,10 +52,9 @@ def assemble_and_size(lines, mcpu):
     directives (so that the disassembly holds exactly the instructions written) and matched function by function: the
     object orders its sections differently from the text."""
     body = [l for l in lines if not re.match(r"\s*\.p2align", l)]
-    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+    src, obj = os.path.join(TMP.name, "sized.s"), os.path.join(TMP.name, "sized.o")
+    with open(src, "w") as f:
         f.write("\n".join(body) + "\n")
-        src = f.name
-    obj = src[:-2] + ".o"
     r = subprocess.run([LLVM + "clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={mcpu}", "-c", src, "-o", obj],
                        capture_output=True, text=True)
     if r.returncode:
@@ -95,12 +96,11 @@ def promotable_forms(texts, mcpu):
     # one file per attempt round: drop the lines the assembler rejects
     alive = list(range(len(texts)))
     while alive:
-        with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        src, obj = os.path.join(TMP.name, "forms.s"), os.path.join(TMP.name, "forms.o")
+        with open(src, "w") as f:
             f.write(f'.amdgcn_target "amdgcn-amd-amdhsa--{mcpu}"\n.text\n')
             for i in alive:
                 f.write(cand[i] + "\n")
-            src = f.name
-        obj = src[:-2] + ".o"
         r = subprocess.run([LLVM + "clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={mcpu}", "-c", src, "-o", obj],
                            capture_output=True, text=True)
         if r.returncode == 0:

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Developer soak: the randomized differential test of tests/test_gpu_parity.py with many more cases and wider ranges
 (float64 both lane layouts, float32 packed / scalar, 4 / 6 waves, trajectories, failing points, every check mode) against
-the oracle.  Usage: python tools/soak_differential.py [seconds] [seed]"""
-import os, sys, time
+the oracle.  Usage: python tools/soak_differential.py [seconds] [seed]
+SOAK_DETAIL=<k> stops after case k (a fixed case list: with it the run also prints a SHA-256 over every output array, so two
+builds of the library -- PSA_HIP_LIB selects one -- can be compared bit for bit)."""
+import hashlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +29,7 @@ t0 = time.time()
 case = fails = 0
 worst = {"f64": 0.0, "f32": 0.0}
 stop_at = int(os.environ.get("SOAK_DETAIL", "0"))
+digest = hashlib.sha256()
 while time.time() - t0 < budget and not (stop_at and case >= stop_at):
     case += 1
     N = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 3000))]))
@@ -58,6 +61,9 @@ while time.time() - t0 < budget and not (stop_at and case >= stop_at):
                   dbeta2=(None if db2 is None else np.asarray(db2, float)))
     got = nat.sweep_host(db, n_steps=n, z_max=L, save_every=se, gamma=gamma, alpha=alpha, a0=a0, dbeta2=db2, check_nan=check,
                          exact_step=exact, want_traj=traj, extra_flags=flags, dtype=(np.float32 if f32 else np.float64))
+    for k in ("a_end", "p_end", "p_max", "first_bad_step", "traj"):
+        if got.get(k) is not None:
+            digest.update(np.ascontiguousarray(got[k]).tobytes())
     ok_pts = ref["first_bad_step"] < 0
     if hot >= 0:   # a hot point that happens to stay finite carries hundreds of radians of nonlinear phase: chaotic, any two
         ok_pts = ok_pts.copy()          # correctly rounded implementations differ by O(1) there (one-lane vs two-lane vs oracle)
@@ -98,5 +104,7 @@ while time.time() - t0 < budget and not (stop_at and case >= stop_at):
         print("FAIL", tag, "errs", errs, "bad_ok", bad_ok, "got_bad", got["first_bad_step"][:8], "ref_bad", ref["first_bad_step"][:8], flush=True)
     if case % 200 == 0:
         print(f"{case} cases, {fails} failures, worst f64 {worst['f64']:.2e} f32 {worst['f32']:.2e}, {time.time() - t0:.0f} s", flush=True)
+if stop_at:
+    print(f"outputs of the {case} cases, SHA-256: {digest.hexdigest()}  (library: {os.environ.get('PSA_HIP_LIB', 'default')})")
 print(f"done: {case} cases, {fails} failures, worst f64 {worst['f64']:.2e}, worst f32 {worst['f32']:.2e}")
 sys.exit(1 if fails else 0)

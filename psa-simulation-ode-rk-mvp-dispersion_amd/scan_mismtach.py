@@ -2,6 +2,8 @@
 
 * ``plot_max_signal_gain_vs_lambda_signal(...) -> (x, gain_max)``            reference scan_mismtach.py:262-430
 * ``plot_max_gain_and_dbeta_vs_lambda_signal(...) -> (x, gain_max, dbeta)``  reference scan_mismtach.py:588-783
+* ``plot_dbeta_vs_lambda_signal(...) -> (x, dbeta)``: what reference scan_mismtach.py:473-585 sets out to return (there every
+  point comes back NaN: its ``_omega0_from_dispersion`` looks for a field the dataclass does not have)
 * ``scan_dbeta_seeded_signal(...)``: a working direct-dbeta scan with gain_mode "end" | "max" and the
   argmax-over-sweep summary -- what the reference's dead ``scan_mismatch_seeded_signal`` (:43-259) set out to do.
 * ``scan_gain_grid(...)``: the same sweep over a 2-D (pump-2 wavelength x signal wavelength) grid in one launch
@@ -399,6 +401,66 @@ def plot_max_gain_and_dbeta_vs_lambda_signal(*, cfg: SimulationConfig, lambda_p1
 
     _maybe_plot(draw, save_path, show)
     return x, gain, dbeta
+
+
+def plot_dbeta_vs_lambda_signal(*, gamma: float, lambda_p1_m: float, lambda_p2_m: float, lambda_signal_m: Sequence[float],
+                                p_in: Sequence[float], dispersion: DispersionParams, return_wavelength_unit: str = "nm",
+                                xscale: str = "linear", yscale: str = "linear", length_unit: str = "m",
+                                show_progress: bool = True, tqdm_desc: str = "Scanning dBeta(λ3)",
+                                title: Optional[str] = None, save_path: Optional[str] = None, show: bool = True,
+                                device: Optional[int] = None, dbeta_producer: str = "auto"
+                                ) -> Tuple[np.ndarray, np.ndarray]:
+    """dbeta(lambda3) = beta(w1) + beta(w2) - beta(w3) - beta(w4) with beta by its Taylor series through order 4, next to the
+    line gamma*(P1 + P2) -> (x, dbeta); dbeta in 1/(the length unit of the dispersion coefficients).
+
+    The call surface, argument checks and NaN-per-failed-point rule of reference scan_mismtach.py:473-585.  Upstream the
+    function returns NaN for every point (its helper asks the dispersion object for ``omega0``, the field is ``omega_ref``,
+    and the exception is swallowed: SURVEY R3); the quantity its docstring and ``_beta_taylor`` (:441-459) describe is the
+    reference's own ``delta_beta_from_omegas`` (dispersion.py:282-318, beta0 and beta1 cancel by energy conservation), which
+    is what is returned here -- through the array producer, or the device one for 4 096 points or more.
+    """
+    lam1, lam2 = float(lambda_p1_m), float(lambda_p2_m)
+    lam3 = np.asarray(list(lambda_signal_m), dtype=float)
+    if lam3.ndim != 1 or lam3.size == 0:
+        raise ValueError("lambda_signal_m must be a non-empty 1D sequence")
+    if not np.all(np.isfinite(lam3)) or np.any(lam3 <= 0.0):
+        raise ValueError("lambda_signal_m must contain finite positive wavelengths (m)")
+    p0 = np.asarray(list(p_in), dtype=float)
+    if p0.shape != (4,):
+        raise ValueError(f"p_in must have shape (4,), got {p0.shape}")
+    if not np.all(np.isfinite(p0)) or np.any(p0 < 0.0):
+        raise ValueError("p_in must contain finite non-negative powers")
+    xs = _norm_choice(xscale, "xscale", ("linear", "log"))
+    ys = _norm_choice(yscale, "yscale", ("linear", "log"))
+    if dispersion is None:
+        raise ValueError("dispersion must be provided to compute dBeta(λ3)")
+
+    pm_cfg = PhaseMatchingConfig(method=PhaseMatchingMethod.GENERAL_TAYLOR, max_order=4, atol=0.0, rtol=1e-12)
+    producer = _pick_producer(dbeta_producer, lam3.size, dispersion, pm_cfg)
+    dbeta, _ = _grid_dbeta(lam1, np.array([lam2]), lam3, dispersion, pm_cfg, producer, 0 if device is None else int(device))
+    x, x_label = _wavelength_axis(lam3, return_wavelength_unit)
+    y_unit = "1/km" if str(length_unit).strip().lower() == "km" else "1/m"
+    ref_line = float(gamma) * float(p0[0] + p0[1])
+    if ys == "log" and (not np.nanmin(dbeta) > 0.0 or ref_line <= 0.0):     # all-NaN counts as "not > 0" (upstream: a warning + NaN)
+        raise ValueError("yscale='log' requires dBeta and gamma*(P1+P2) to be strictly > 0.")
+
+    def draw(plt):
+        fig = plt.figure(figsize=(8.0, 5.0))
+        plt.plot(x, dbeta, label=r"$d\beta(\lambda_3)$")
+        plt.axhline(ref_line, linestyle="--", label=r"$\gamma(P_1+P_2)$")
+        plt.xlabel(x_label)
+        plt.ylabel(rf"$d\beta$ [{y_unit}]")
+        plt.xscale(xs)
+        plt.yscale(ys)
+        if title is not None:
+            plt.title(title)
+        plt.grid(True, which="both", linestyle="--", alpha=0.5)
+        plt.legend()
+        plt.tight_layout()
+        return fig
+
+    _maybe_plot(draw, save_path, show)
+    return x, dbeta
 
 
 def scan_dbeta_seeded_signal(*, cfg: SimulationConfig, delta_beta: Sequence[float], gamma, alpha,

@@ -324,16 +324,16 @@ def test_g13_host_producers_against_the_reference_grid_rows(golden):
 def test_public_call_surface_equals_the_reference(golden):
     """tests/golden/api_signatures.json (written by gen_golden.py from the reference): every public function of the
     hot-path modules exists here with the same parameter names, kinds and defaults, and every public dataclass with the same
-    fields, so reference code switches by changing imports.  The two functions upstream cannot run
-    (scan_mismatch_seeded_signal passes a keyword run_single_simulation does not have; plot_dbeta_vs_lambda_signal calls
-    undefined names -- SURVEY R2) have a working counterpart instead: scan_dbeta_seeded_signal."""
+    fields, so reference code switches by changing imports.  scan_mismatch_seeded_signal, which upstream
+    cannot run (it passes a keyword run_single_simulation does not have), has a working counterpart instead:
+    scan_dbeta_seeded_signal; plot_dbeta_vs_lambda_signal (upstream: NaN for every point) keeps its signature."""
     import dataclasses
     import importlib
     import inspect
     import json
     import os
     spec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "api_signatures.json")))
-    dead = {("scan_mismtach", "scan_mismatch_seeded_signal"), ("scan_mismtach", "plot_dbeta_vs_lambda_signal")}
+    dead = {("scan_mismtach", "scan_mismatch_seeded_signal")}
     checked = 0
     for modname, entry in spec.items():
         mod = importlib.import_module("psa_amd." + modname)
@@ -443,3 +443,34 @@ def test_batch_producers_agree_with_the_scalar_api_point_by_point():
             assert np.isnan(db[0])
 
     check()
+
+
+def test_dbeta_only_driver_returns_the_general_taylor_mismatch(golden):
+    """plot_dbeta_vs_lambda_signal: upstream (scan_mismtach.py:473-585) hands back NaN for every point; the
+    quantity it describes is the reference's delta_beta_from_omegas, pinned here by G10's `gen4` column (rtol 1e-14: the
+    array producer's pow may differ from the scalar API by an ulp) and by G9's impossible plan -> NaN."""
+    from psa_amd.scan_mismtach import plot_dbeta_vs_lambda_signal
+    g = golden("G10")
+    dv = g["disp"]
+    d = dispersion.DispersionParams(omega_ref=dv[0], beta2=dv[1], beta3=dv[2], beta4=dv[3], extra={6: dv[4]})
+    kw = dict(gamma=0.0115, p_in=[0.5, 0.5, 1e-5, 0.0], dispersion=d, show=False, show_progress=False)
+    for i in range(len(g["l3"])):
+        x, db = plot_dbeta_vs_lambda_signal(lambda_p1_m=g["lp1"][i], lambda_p2_m=g["lp2"][i], lambda_signal_m=[g["l3"][i]], **kw)
+        assert x[0] == g["l3"][i] * 1e9
+        np.testing.assert_allclose(db[0], g["gen4"][i], rtol=1e-14, atol=0)
+    # a sweep: one impossible plan in the middle is NaN, the others are what the single-point calls give
+    lam3 = np.array([1555e-9, 0.7e-6, 1560e-9])
+    x, db = plot_dbeta_vs_lambda_signal(lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, lambda_signal_m=lam3,
+                                        return_wavelength_unit="m", **kw)
+    assert np.array_equal(x, lam3) and list(np.isnan(db)) == [False, True, False]
+    one = plot_dbeta_vs_lambda_signal(lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, lambda_signal_m=[1560e-9], **kw)[1]
+    assert db[2] == one[0]
+    # the reference's argument checks
+    for bad, msg in ((dict(lambda_signal_m=[]), "non-empty"), (dict(lambda_signal_m=[-1.0]), "finite positive"),
+                     (dict(p_in=[1, 1, 1]), "shape"), (dict(p_in=[1, -1, 1, 1]), "non-negative"),
+                     (dict(xscale="cubic"), "xscale"), (dict(return_wavelength_unit="um"), "return_wavelength_unit"),
+                     (dict(yscale="log"), "strictly > 0")):
+        args = dict(lambda_p1_m=1550e-9, lambda_p2_m=1558e-9, lambda_signal_m=lam3, **kw)
+        args.update(bad)
+        with pytest.raises(ValueError, match=msg):
+            plot_dbeta_vs_lambda_signal(**args)

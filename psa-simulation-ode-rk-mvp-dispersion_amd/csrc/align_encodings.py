@@ -194,6 +194,20 @@ def main():
         off = (off + size) % 8
         run = []
 
+    # PC-relative address sequences (s_getpc_b64 + s_add_u32 / s_addc_u32 with @rel32 literals whose +4 / +12 assume the three
+    # instructions are adjacent) must come through untouched: only VALU encodings change and an s_nop goes directly in front
+    # of an 8-byte VALU instruction, so they do by construction -- checked all the same.
+    def pc_sequences(text_lines):
+        ins = [l.strip() for l in text_lines if l.strip() and l.strip()[0] not in ".;" and not l.split()[0].endswith(":")]
+        return [tuple(ins[k:k + 3]) for k, l in enumerate(ins) if l.startswith("s_getpc_b64")]
+    final = []
+    for n, l in enumerate(out):
+        final.append(l)
+        if n in insert_after:
+            final.extend(insert_after[n].rstrip("\n").split("\n"))
+    if pc_sequences(lines) != pc_sequences(final):
+        raise SystemExit("align_encodings: a PC-relative address sequence would change")
+
     with open(dst, "w") as f:
         for n, l in enumerate(out):
             f.write(l + ("\n" if n + 1 < len(out) else ""))

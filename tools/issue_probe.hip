@@ -98,6 +98,36 @@ KERNEL(abb, R16(ABB_15), 240)
 KERNEL(abbb, R16(ABBB_16), 256)
 KERNEL(aab, R16(AAB_15), 240)
 
+// the whole loop in assembly, so that the position of its first instruction inside a 64-byte line is chosen here:
+// PAD = number of 4-byte s_nop between a 64-byte boundary and the loop label (executed once, before the loop)
+#define ASM_LOOP_KERNEL(NAME, PAD, BODY, PER_ITER)                                                                \
+    __global__ void __launch_bounds__(64) NAME(double *out, long long *cyc, int iters, double m, double c) {      \
+        double a[16];                                                                                              \
+        for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 1e-3 + i;                                                \
+        const long long t0 = __builtin_readcyclecounter();                                                         \
+        asm volatile("s_mov_b32 s20, %18\n\t.p2align 6\n\t" PAD "1:\n\t" BODY                                     \
+                     "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b\n\t"                       \
+                     : ACC_OPS : "v"(m), "v"(c), "s"(iters) : "s20", "scc");                                       \
+        const long long t1 = __builtin_readcyclecounter();                                                         \
+        double s = 0;                                                                                              \
+        for (int i = 0; i < 16; ++i) s += a[i];                                                                    \
+        out[blockIdx.x * 64 + threadIdx.x] = s;                                                                    \
+        if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                                           \
+    }                                                                                                              \
+    static const int NAME##_per_iter = PER_ITER;
+#define NOP2 "s_nop 0\n\ts_nop 0\n\t"
+#define NOP4 NOP2 NOP2
+#define NOP8 NOP4 NOP4
+ASM_LOOP_KERNEL(loop16_at0, "", ALL16, 16)
+ASM_LOOP_KERNEL(loop16_at8, NOP2, ALL16, 16)
+ASM_LOOP_KERNEL(loop16_at16, NOP4, ALL16, 16)
+ASM_LOOP_KERNEL(loop16_at32, NOP8, ALL16, 16)
+ASM_LOOP_KERNEL(loop16_at48, NOP8 NOP4, ALL16, 16)
+ASM_LOOP_KERNEL(loop16_at56, NOP8 NOP4 NOP2, ALL16, 16)
+ASM_LOOP_KERNEL(loop64_at0, "", R4(ALL16), 64)
+ASM_LOOP_KERNEL(loop64_at32, NOP8, R4(ALL16), 64)
+ASM_LOOP_KERNEL(loop64_at56, NOP8 NOP4 NOP2, R4(ALL16), 64)
+
 typedef void (*kern_t)(double *, long long *, int, double, double);
 
 static void run(const char *name, kern_t k, int per_iter, int waves_per_simd, long long total_instr) {
@@ -145,6 +175,8 @@ int main(int argc, char **argv) {
         RUN(dep1, w); RUN(dep2, w); RUN(dep3, w); RUN(dep4, w);
         RUN(odd256, w); RUN(even256, w); RUN(e32_256, w);
         RUN(ind256_off4, w); RUN(pk_off4, w); RUN(ab_off4, w); RUN(a4b4_off4, w);
+        RUN(loop16_at0, w); RUN(loop16_at8, w); RUN(loop16_at16, w); RUN(loop16_at32, w); RUN(loop16_at48, w); RUN(loop16_at56, w);
+        RUN(loop64_at0, w); RUN(loop64_at32, w); RUN(loop64_at56, w);
         RUN(fmac_e64, w); RUN(mul_e64, w); RUN(fma_const, w); RUN(pk_fma, w);
         RUN(ab, w); RUN(a2b2, w); RUN(a4b4, w); RUN(a8b8, w); RUN(a16b16, w); RUN(a32b32, w); RUN(abb, w); RUN(abbb, w); RUN(aab, w);
     }
